@@ -1,0 +1,264 @@
+/*
+ * kkdirect.h -- C ABI of libkkdirect.so, the MI355X (gfx950) implementation of the
+ * "kkIntegrator" direct-lighting path of akaterin/ray-tracer (a Mitsuba 0.5 fork).
+ *
+ * The boundary: the reference's plugin `plugins/kkIntegrator.so`
+ * (src/integrators/SConscript:44, src/integrators/kk/direct.cpp:15-199) is a
+ * SamplingIntegrator whose per-sample work is SamplingIntegrator::renderBlock
+ * (src/librender/integrator.cpp:140-188) + DirectIntegrator::Li
+ * (src/integrators/kk/direct.cpp:50-178).  A replacement plugin overrides
+ * Integrator::render() (src/librender/integrator.cpp:95-129; precedent
+ * src/integrators/kk/vcm.cpp:196-218), flattens the scene through the public
+ * Scene/TriMesh/BSDF/Emitter API and calls the functions below.  Every entry
+ * point cites the reference interface it replaces.
+ *
+ * Plain C: pointers and sizes only, no C++ types, no exceptions cross it.
+ * All functions return KKD_OK (0) or a negative KKD_ERR_* code; the text of the
+ * last error of a context is available from kkd_last_error().  One context is
+ * used from one host thread at a time (kkd_request_cancel excepted).
+ *
+ * Conventions (same as the reference, SINGLE_PRECISION / SPECTRUM_SAMPLES=3):
+ *   Float = float32, Spectrum = linear RGB triple, matrices row-major,
+ *   film pixel = 5 floats {R*w, G*w, B*w, alpha*w, w}  (Bitmap::ESpectrumAlphaWeight,
+ *   src/librender/renderproc.cpp:121, src/films/hdrfilm.cpp:352).
+ */
+#ifndef KKDIRECT_H
+#define KKDIRECT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KKD_ABI_VERSION 1
+
+/* ---- error codes ---------------------------------------------------------------- */
+#define KKD_OK              0
+#define KKD_ERR_INVALID    (-1)  /* bad argument / inconsistent scene description      */
+#define KKD_ERR_DEVICE     (-2)  /* HIP runtime error (text in kkd_last_error)          */
+#define KKD_ERR_CANCELLED  (-3)  /* kkd_request_cancel() was honoured                   */
+#define KKD_ERR_NOMEM      (-4)
+#define KKD_ERR_UNSUPPORTED (-5) /* feature outside the hot path (e.g. bsdfSamples==0)  */
+
+/* ---- enums ----------------------------------------------------------------------- */
+/* BSDF models on the path: src/bsdfs/{diffuse,roughconductor,roughplastic,dielectric,twosided}.cpp */
+#define KKD_BSDF_DIFFUSE         0
+#define KKD_BSDF_ROUGHCONDUCTOR  1
+#define KKD_BSDF_ROUGHPLASTIC    2
+#define KKD_BSDF_DIELECTRIC      3
+#define KKD_BSDF_TWOSIDED        4
+
+/* MicrofacetDistribution::EType, src/bsdfs/microfacet.h:48-57 */
+#define KKD_DISTR_BECKMANN 0
+#define KKD_DISTR_GGX      1
+#define KKD_DISTR_PHONG    2
+
+/* Emitters on the path: src/emitters/{area,point,envmap}.cpp */
+#define KKD_EMITTER_AREA   0
+#define KKD_EMITTER_POINT  1
+#define KKD_EMITTER_ENVMAP 2
+
+/* reconstruction filters: src/rfilters/ (tabulated by src/libcore/rfilter.cpp:37-55) */
+#define KKD_RFILTER_GAUSSIAN   0
+#define KKD_RFILTER_BOX        1
+#define KKD_RFILTER_TENT       2
+#define KKD_RFILTER_MITCHELL   3
+#define KKD_RFILTER_CATMULLROM 4
+#define KKD_RFILTER_LANCZOS    5
+
+/* shape flags */
+#define KKD_SHAPE_HAS_NORMALS   1u  /* per-vertex normals valid for this shape (TriMesh::m_normals != NULL) */
+#define KKD_SHAPE_HAS_TEXCOORDS 2u  /* per-vertex uv valid (TriMesh::m_texcoords != NULL)                   */
+
+/* multi-GPU split mode */
+#define KKD_SPLIT_TILE   0
+#define KKD_SPLIT_SAMPLE 1
+
+/* ---- scene description ------------------------------------------------------------ */
+
+/* One Mitsuba Shape after Scene::addShape expansion (src/librender/scene.cpp:558-591); the
+ * order of this array is the ShapeKDTree::addShape order (src/librender/skdtree.cpp:49-66), so
+ * global primitive id = first_prim + local primIndex (skdtree.cpp:57-58,69-70). */
+typedef struct kkd_shape {
+    uint32_t first_prim;    /* index of the shape's first triangle in kkd_scene_desc.indices   */
+    uint32_t n_prims;       /* TriMesh::getTriangleCount()                                      */
+    int32_t  material_id;   /* index into materials (Shape::getBSDF())                          */
+    int32_t  emitter_id;    /* index into emitters or -1 (Shape::getEmitter())                  */
+    uint32_t flags;         /* KKD_SHAPE_*                                                      */
+    uint32_t reserved;
+} kkd_shape;
+
+/* BSDF parameter block.  Holds the *configured* state of the plugin, i.e. what the reference
+ * serialises (diffuse.cpp:161-165, roughconductor.cpp:216-226, roughplastic.cpp:243-253,
+ * dielectric.cpp:176-182, twosided.cpp:77-82); textures must be constant. */
+typedef struct kkd_material {
+    int32_t type;              /* KKD_BSDF_*                                                  */
+    int32_t distribution;      /* KKD_DISTR_* (rough models)                                  */
+    int32_t sample_visible;    /* MicrofacetDistribution::m_sampleVisible (default 1)         */
+    int32_t nonlinear;         /* roughplastic 'nonlinear'                                    */
+    int32_t nested[2];         /* twosided: material ids of m_nestedBRDF[0..1] (-1: same as 0) */
+    float   alpha_u, alpha_v;  /* roughness (clamped to >=1e-4 by the library as microfacet.h:70-71) */
+    float   eta;               /* dielectric / roughplastic: intIOR/extIOR                    */
+    float   reflectance[3];            /* diffuse 'reflectance' / roughplastic 'diffuseReflectance' */
+    float   specular_reflectance[3];   /* 'specularReflectance' (default 1)                   */
+    float   specular_transmittance[3]; /* dielectric 'specularTransmittance' (default 1)      */
+    float   cond_eta[3];       /* roughconductor eta / extEta  (roughconductor.cpp:189)       */
+    float   cond_k[3];         /* roughconductor k   / extEta  (roughconductor.cpp:190)       */
+} kkd_material;
+
+/* Emitter record.  Area lights reference their parent shape (emitters/area.cpp:185-202). */
+typedef struct kkd_emitter {
+    int32_t type;              /* KKD_EMITTER_*                                               */
+    int32_t shape_id;          /* area: parent shape index; else -1                           */
+    float   sampling_weight;   /* Emitter::getSamplingWeight() (emitter.cpp:100-104)          */
+    float   radiance[3];       /* area: 'radiance'; point: 'intensity'; envmap: unused        */
+    float   position[3];       /* point: world position                                       */
+    float   reserved;
+} kkd_emitter;
+
+/* Environment map (emitters/envmap.cpp).  Texels are the level-0 MIP array, linear RGB float32,
+ * row-major, row 0 = +Y pole (theta = 0).  The library rounds them to half precision like the
+ * reference's TMIPMap<Spectrum, SpectrumHalf> storage (envmap.cpp:102-103). */
+typedef struct kkd_envmap {
+    uint32_t width, height;    /* 0,0 => no environment emitter                               */
+    const float *texels;       /* width*height*3                                              */
+    float   scale;             /* 'scale' (envmap.cpp:188)                                    */
+    float   to_world[9];       /* rotation part of toWorld, row-major 3x3                     */
+    float   bsphere_center[3]; /* m_sceneBSphere as set by EnvironmentMap::createShape        */
+    float   bsphere_radius;    /* (envmap.cpp:331-341): 1.5 x radius of the scene AABB sphere */
+} kkd_envmap;
+
+/* Perspective sensor + film + filter (sensors/perspective.cpp:126-180, librender/sensor.cpp:84-108,
+ * librender/film.cpp:25-96). */
+typedef struct kkd_sensor {
+    float   to_world[16];      /* camera-to-world, row-major 4x4, no scale (perspective.cpp:116-118) */
+    float   xfov_deg;          /* PerspectiveCamera::getXFov()                                 */
+    float   near_clip, far_clip;
+    uint32_t film_width, film_height;       /* Film::getSize()                                 */
+    uint32_t crop_offset_x, crop_offset_y;  /* Film::getCropOffset()                           */
+    uint32_t crop_width, crop_height;       /* Film::getCropSize()                             */
+    int32_t  film_has_alpha;   /* Film::hasAlpha() (integrator.cpp:159-160)                    */
+    int32_t  rfilter_type;     /* KKD_RFILTER_*                                                */
+    float    rfilter_radius;   /* gaussian: 4*stddev (=2); box: 0.5(+1e-5); tent 1; mitchell/catmullrom 2; lanczos: lobes */
+    float    rfilter_param[2]; /* gaussian: stddev,-; mitchell: B,C; lanczos: lobes,-          */
+} kkd_sensor;
+
+typedef struct kkd_scene_desc {
+    uint32_t abi_version;      /* = KKD_ABI_VERSION                                            */
+    uint32_t reserved0;
+    /* geometry: all TriMeshes concatenated, indices already offset into the global vertex arrays */
+    uint64_t n_verts, n_tris;
+    const float    *positions; /* n_verts*3  (TriMesh::getVertexPositions)                     */
+    const float    *normals;   /* n_verts*3 or NULL (TriMesh::getVertexNormals)                */
+    const float    *texcoords; /* n_verts*2 or NULL (TriMesh::getVertexTexcoords)              */
+    const uint32_t *indices;   /* n_tris*3   (TriMesh::getTriangles)                           */
+    uint32_t n_shapes;  const kkd_shape    *shapes;
+    uint32_t n_materials; const kkd_material *materials;
+    uint32_t n_emitters;  const kkd_emitter  *emitters;   /* Scene::getEmitters() order        */
+    kkd_envmap envmap;         /* referenced by the emitter of type KKD_EMITTER_ENVMAP         */
+    kkd_sensor sensor;
+} kkd_scene_desc;
+
+/* ---- context / render parameters ----------------------------------------------------- */
+
+typedef struct kkd_config {
+    int32_t  device;           /* HIP device ordinal                                           */
+    int32_t  split_mode;       /* KKD_SPLIT_*; informational (the caller shards, see kkd_render_params) */
+    uint64_t seed;             /* RNG seed: key = (seed, pixel), counter = (sample, dimension) */
+    uint64_t max_samples_in_flight; /* 0 = library default; bounds the wavefront buffers       */
+} kkd_config;
+
+/* integrator parameters = the XML parameters of the plugin (kk/direct.cpp:17-21) + the
+ * work-unit description that replaces RectangularWorkUnit (librender/rectwu.cpp:33-49). */
+typedef struct kkd_render_params {
+    uint32_t spp;              /* Sampler::getSampleCount() (integrator.cpp:103-104)           */
+    uint32_t bsdf_samples;     /* 'bsdfSamples'  (default 1)                                   */
+    uint32_t light_samples;    /* 'lightSamples' (default 1)                                   */
+    int32_t  hide_emitters;    /* 'hideEmitters' (default false)                               */
+    /* sharding: render only tiles t with t % tile_count == tile_index (tile mode), and only sample
+     * indices [sample_first, sample_first+spp) of each pixel (sample-split mode).               */
+    uint32_t block_size;       /* tile edge in pixels, 0 = 32 (scene.cpp:24)                   */
+    uint32_t tile_index, tile_count;  /* 0,1 (or 0,0) = all tiles                              */
+    uint32_t sample_first;     /* first RNG sample index (0)                                   */
+} kkd_render_params;
+
+typedef struct kkd_stats {
+    uint64_t samples;          /* camera samples processed                                     */
+    uint64_t rays_closest;     /* "Normal rays traced"  (skdtree.cpp:46,123)                    */
+    uint64_t rays_shadow;      /* "Shadow rays traced"  (skdtree.cpp:47,151,210)                */
+    double   seconds;          /* device time of the render loop (HIP events)                  */
+    double   seconds_trace;    /* part of it spent in the traversal kernels                    */
+    double   algorithmic_bytes;/* sum over rays of B_ray + B_shade + B_splat        */
+    uint64_t nodes_visited;    /* filled when KKD_COUNT_TRAVERSAL is requested via kkd_trace_counted */
+    uint64_t tris_tested;
+} kkd_stats;
+
+typedef struct kkd_hit {       /* IntersectionCache of skdtree.h: {shapeIndex, primIndex, u, v} + t */
+    float    t;                /* +inf on miss                                                 */
+    float    u, v;             /* barycentrics of vertices 1 and 2 (triaccel.h)                */
+    uint32_t prim;             /* global primitive id (shape first_prim + primIndex), 0xFFFFFFFF on miss */
+} kkd_hit;
+
+typedef struct kkd_ctx kkd_ctx;
+
+/* ---- entry points ---------------------------------------------------------------------- */
+
+/* Number of usable HIP devices.  Replaces Scheduler::getCoreCount() in the log line of
+ * SamplingIntegrator::render (src/librender/integrator.cpp:102-109). */
+int kkd_device_count(void);
+
+/* Create a context on one device.  Replaces the per-process state BlockedRenderProcess /
+ * BlockRenderer hold (src/librender/renderproc.cpp:26-66).  NULL on failure. */
+kkd_ctx *kkd_create(const kkd_config *cfg);
+
+/* Copy the flattened scene to the device, build the BVH, the emitter CDFs
+ * (Scene::initialize, src/librender/scene.cpp:376-380; TriMesh::prepareSamplingTable,
+ * src/librender/trimesh.cpp:392-407; EnvironmentMap::configure, src/emitters/envmap.cpp:260-329),
+ * the rough-transmittance tables (src/bsdfs/rtrans.h:288-384) and the filter table
+ * (src/libcore/rfilter.cpp:37-55).  Replaces Scene::preprocess -> ShapeKDTree::build
+ * (src/librender/skdtree.cpp:68-110).  The caller keeps ownership of all input arrays. */
+int kkd_scene_upload(kkd_ctx *ctx, const kkd_scene_desc *scene);
+
+/* Render: the body of SamplingIntegrator::render + renderBlock + DirectIntegrator::Li
+ * (src/librender/integrator.cpp:95-188, src/integrators/kk/direct.cpp:50-178).
+ * out_film: crop_width*crop_height*5 floats, host memory, overwritten with the ImageBlock
+ * sums {R*w,G*w,B*w,alpha*w,w} of the samples this call rendered -- hand it to Film::put /
+ * Film::setBitmap (src/films/hdrfilm.cpp:391-397).  stats may be NULL. */
+int kkd_render(kkd_ctx *ctx, const kkd_render_params *params, float *out_film, kkd_stats *stats);
+
+/* Same, but the film stays in device memory: *out_dev_film receives a device pointer owned by
+ * the context (valid until the next render/destroy) so that multi-GPU callers can reduce it with
+ * RCCL without a host round trip (sample-split mode). */
+int kkd_render_device(kkd_ctx *ctx, const kkd_render_params *params, void **out_dev_film, kkd_stats *stats);
+
+/* Fixed-ray-set entry point: ShapeKDTree::rayIntersect(ray, its) when any_hit==0
+ * (src/librender/skdtree.cpp:112-142) and ShapeKDTree::rayIntersect(ray) when any_hit!=0
+ * (skdtree.cpp:207-226), including their adaptive ray epsilon.  rays: n x 8 floats
+ * {o.x,o.y,o.z,mint,d.x,d.y,d.z,maxt} in host memory; out: n kkd_hit in host memory
+ * (any_hit: only prim!=0xFFFFFFFF / t<inf is meaningful). */
+int kkd_trace(kkd_ctx *ctx, const float *rays, uint64_t n, int any_hit, kkd_hit *out);
+
+/* Same with rays and hits resident in device memory (what the bench times). */
+int kkd_trace_device(kkd_ctx *ctx, const void *dev_rays, uint64_t n, int any_hit, void *dev_out, kkd_stats *stats);
+
+/* Counting variant of kkd_trace (host buffers): also reports visited nodes / tested triangles in
+ * stats->nodes_visited / tris_tested, the measured N_nodes and N_tris of SURVEY 8d. */
+int kkd_trace_counted(kkd_ctx *ctx, const float *rays, uint64_t n, int any_hit, kkd_hit *out, kkd_stats *stats);
+
+/* Sizes of the acceleration-structure records, for the algorithmic-bytes formula of SURVEY 8d. */
+int kkd_accel_info(kkd_ctx *ctx, uint32_t *node_bytes, uint32_t *tri_bytes, uint64_t *n_nodes, uint64_t *n_leaf_tris);
+
+/* Asynchronous, thread-safe: replaces SamplingIntegrator::cancel (src/librender/integrator.cpp:90-93). */
+void kkd_request_cancel(kkd_ctx *ctx);
+
+/* Mitsuba convention is Log(EError, ...) -> exception (src/librender/renderjob.cpp:111-115); here the
+ * text is kept per context.  Never NULL.  ctx == NULL returns the last error of kkd_create. */
+const char *kkd_last_error(kkd_ctx *ctx);
+
+void kkd_destroy(kkd_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KKDIRECT_H */

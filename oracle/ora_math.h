@@ -1,0 +1,276 @@
+/*
+ * ORACLE (test infrastructure, never shipped, never measured as the product):
+ * CPU restatement of the Mitsuba-0.5 math used by the kk direct-lighting path.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+ *
+ * Follows (reference file:line, relative to /root/reference/src):
+ *   libcore/util.cpp:591-600   coordinateSystem
+ *   libcore/util.cpp:446-484   solveQuadratic
+ *   libcore/util.cpp:612-655   fresnelDielectricExt
+ *   libcore/util.cpp:713-735   fresnelConductorExact (spectral)
+ *   libcore/warp.cpp:25-31,43-52,76-102,143-162  warps
+ *   libcore/math.cpp:25-72     erfinv / erf
+ *   libcore/random.cpp:630-639 uint32 -> float in [0,1) with 23 random bits
+ * Absent-header semantics (frame.h, math.h, bsphere.h, aabb.h) are taken from SURVEY.md 9.5.
+ *
+ * The random source is NOT the reference's SFMT-19937: per SURVEY 0.5 the path uses a
+ * counter-based generator (Philox4x32-10), restated here so that oracle and device draw the
+ * same numbers for (seed, pixel, sample, dimension).
+ */
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <algorithm>
+#include <limits>
+
+namespace ora {
+
+typedef float Float;
+static const Float kPi = 3.14159265358979323846f;
+static const Float kInvPi = 0.31830988618379067154f;
+static const Float kInvTwoPi = 0.15915494309189533577f;
+static const Float kEpsilon = 1e-4f;        /* Epsilon, single precision      */
+static const Float kShadowEpsilon = 1e-3f;  /* ShadowEpsilon                  */
+static const Float kDeltaEpsilon = 1e-3f;   /* DeltaEpsilon                   */
+
+struct V2 { Float x, y; };
+struct V3 {
+    Float x, y, z;
+    V3() : x(0), y(0), z(0) {}
+    V3(Float a, Float b, Float c) : x(a), y(b), z(c) {}
+    explicit V3(Float a) : x(a), y(a), z(a) {}
+    Float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+    Float &operator[](int i) { return i == 0 ? x : (i == 1 ? y : z); }
+};
+inline V3 operator+(V3 a, V3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V3 operator-(V3 a, V3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V3 operator-(V3 a) { return V3(-a.x, -a.y, -a.z); }
+inline V3 operator*(V3 a, Float s) { return V3(a.x * s, a.y * s, a.z * s); }
+inline V3 operator*(Float s, V3 a) { return V3(a.x * s, a.y * s, a.z * s); }
+inline V3 operator*(V3 a, V3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+inline V3 operator/(V3 a, Float s) { return V3(a.x / s, a.y / s, a.z / s); }
+inline V3 operator/(V3 a, V3 b) { return V3(a.x / b.x, a.y / b.y, a.z / b.z); }
+inline V3 &operator+=(V3 &a, V3 b) { a = a + b; return a; }
+inline V3 &operator*=(V3 &a, Float s) { a = a * s; return a; }
+inline Float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline Float absDot(V3 a, V3 b) { return std::fabs(dot(a, b)); }
+inline V3 cross(V3 a, V3 b) {
+    return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+inline Float lengthSquared(V3 a) { return dot(a, a); }
+inline Float length(V3 a) { return std::sqrt(dot(a, a)); }
+inline V3 normalize(V3 a) { return a / length(a); }
+inline bool isZero(V3 a) { return a.x == 0 && a.y == 0 && a.z == 0; }
+inline Float maxComp(V3 a) { return std::max(a.x, std::max(a.y, a.z)); }
+inline V3 sqrtSafe(V3 a) {
+    return V3(std::sqrt(std::max(a.x, 0.f)), std::sqrt(std::max(a.y, 0.f)), std::sqrt(std::max(a.z, 0.f)));
+}
+/* Spectrum::getLuminance for linear sRGB (RGB mode of Mitsuba 0.5 spectrum.h) */
+inline Float luminance(V3 c) { return c.x * 0.212671f + c.y * 0.715160f + c.z * 0.072169f; }
+
+inline Float safe_sqrt(Float v) { return std::sqrt(std::max(0.f, v)); }
+inline Float safe_acos(Float v) { return std::acos(std::min(1.f, std::max(-1.f, v))); }
+inline Float signum(Float v) { return std::copysign(1.0f, v); }
+
+/* libcore/util.cpp:591-600 */
+inline void coordinateSystem(V3 a, V3 &b, V3 &c) {
+    if (std::fabs(a.x) > std::fabs(a.y)) {
+        Float invLen = 1.0f / std::sqrt(a.x * a.x + a.z * a.z);
+        c = V3(a.z * invLen, 0.0f, -a.x * invLen);
+    } else {
+        Float invLen = 1.0f / std::sqrt(a.y * a.y + a.z * a.z);
+        c = V3(0.0f, a.z * invLen, -a.y * invLen);
+    }
+    b = cross(c, a);
+}
+
+/* frame.h (absent) */
+struct Frame {
+    V3 s, t, n;
+    Frame() {}
+    explicit Frame(V3 nn) : n(nn) { coordinateSystem(nn, s, t); }
+    V3 toLocal(V3 v) const { return V3(dot(v, s), dot(v, t), dot(v, n)); }
+    V3 toWorld(V3 v) const { return s * v.x + t * v.y + n * v.z; }
+    static Float cosTheta(V3 v) { return v.z; }
+    static Float cosTheta2(V3 v) { return v.z * v.z; }
+    static Float sinTheta2(V3 v) { return 1.0f - v.z * v.z; }
+    static Float tanTheta(V3 v) {
+        Float temp = 1 - v.z * v.z;
+        if (temp <= 0.0f) return 0.0f;
+        return std::sqrt(temp) / v.z;
+    }
+};
+
+/* libcore/util.cpp:446-484 */
+inline bool solveQuadratic(Float a, Float b, Float c, Float &x0, Float &x1) {
+    if (a == 0) {
+        if (b != 0) { x0 = x1 = -c / b; return true; }
+        return false;
+    }
+    Float discrim = b * b - 4.0f * a * c;
+    if (discrim < 0) return false;
+    Float temp, sq = std::sqrt(discrim);
+    if (b < 0) temp = -0.5f * (b - sq); else temp = -0.5f * (b + sq);
+    x0 = temp / a;
+    x1 = c / temp;
+    if (x0 > x1) std::swap(x0, x1);
+    return true;
+}
+
+/* bsphere.h (absent): ray/sphere via solveQuadratic */
+inline bool bsphereRayIntersect(V3 center, Float radius, V3 o, V3 d, Float &nearT, Float &farT) {
+    V3 oc = o - center;
+    Float A = lengthSquared(d), B = 2 * dot(oc, d), C = lengthSquared(oc) - radius * radius;
+    return solveQuadratic(A, B, C, nearT, farT);
+}
+
+/* ---- Fresnel ------------------------------------------------------------------------- */
+/* libcore/util.cpp:625-655 */
+inline Float fresnelDielectricExt(Float cosThetaI_, Float &cosThetaT_, Float eta) {
+    if (eta == 1) { cosThetaT_ = -cosThetaI_; return 0.0f; }
+    Float scale = (cosThetaI_ > 0) ? 1 / eta : eta,
+          cosThetaTSqr = 1 - (1 - cosThetaI_ * cosThetaI_) * (scale * scale);
+    if (cosThetaTSqr <= 0.0f) { cosThetaT_ = 0.0f; return 1.0f; }
+    Float cosThetaI = std::fabs(cosThetaI_);
+    Float cosThetaT = std::sqrt(cosThetaTSqr);
+    Float Rs = (cosThetaI - eta * cosThetaT) / (cosThetaI + eta * cosThetaT);
+    Float Rp = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+    cosThetaT_ = (cosThetaI_ > 0) ? -cosThetaT : cosThetaT;
+    return 0.5f * (Rs * Rs + Rp * Rp);
+}
+inline Float fresnelDielectricExt(Float cosThetaI, Float eta) {
+    Float t; return fresnelDielectricExt(cosThetaI, t, eta);
+}
+
+/* libcore/util.cpp:713-735 */
+inline V3 fresnelConductorExact(Float cosThetaI, V3 eta, V3 k) {
+    Float cosThetaI2 = cosThetaI * cosThetaI, sinThetaI2 = 1 - cosThetaI2, sinThetaI4 = sinThetaI2 * sinThetaI2;
+    V3 temp1 = eta * eta - k * k - V3(sinThetaI2),
+       a2pb2 = sqrtSafe(temp1 * temp1 + k * k * eta * eta * 4),
+       a = sqrtSafe((a2pb2 + temp1) * 0.5f);
+    V3 term1 = a2pb2 + V3(cosThetaI2), term2 = a * (2 * cosThetaI);
+    V3 Rs2 = (term1 - term2) / (term1 + term2);
+    V3 term3 = a2pb2 * cosThetaI2 + V3(sinThetaI4), term4 = term2 * sinThetaI2;
+    V3 Rp2 = Rs2 * (term3 - term4) / (term3 + term4);
+    return 0.5f * (Rp2 + Rs2);
+}
+
+/* ---- warps (libcore/warp.cpp) ---------------------------------------------------------- */
+inline V3 squareToUniformSphere(V2 s) {
+    Float z = 1.0f - 2.0f * s.y;
+    Float r = safe_sqrt(1.0f - z * z);
+    Float sinPhi = std::sin(2.0f * kPi * s.x), cosPhi = std::cos(2.0f * kPi * s.x);
+    return V3(r * cosPhi, r * sinPhi, z);
+}
+inline V2 squareToUniformDiskConcentric(V2 s) {
+    Float r1 = 2.0f * s.x - 1.0f, r2 = 2.0f * s.y - 1.0f;
+    Float phi, r;
+    if (r1 == 0 && r2 == 0) { r = phi = 0; }
+    else if (r1 * r1 > r2 * r2) { r = r1; phi = (kPi / 4.0f) * (r2 / r1); }
+    else { r = r2; phi = (kPi / 2.0f) - (r1 / r2) * (kPi / 4.0f); }
+    return V2{ r * std::cos(phi), r * std::sin(phi) };
+}
+inline V3 squareToCosineHemisphere(V2 s) {
+    V2 p = squareToUniformDiskConcentric(s);
+    Float z = safe_sqrt(1.0f - p.x * p.x - p.y * p.y);
+    if (z == 0) z = 1e-10f;
+    return V3(p.x, p.y, z);
+}
+inline Float squareToCosineHemispherePdf(V3 d) { return kInvPi * d.z; }
+inline V2 squareToUniformTriangle(V2 s) {
+    Float a = safe_sqrt(1.0f - s.x);
+    return V2{ 1 - a, a * s.y };
+}
+inline Float intervalToTent(Float s) {
+    Float sign;
+    if (s < 0.5f) { sign = 1; s *= 2; } else { sign = -1; s = 2 * (s - 0.5f); }
+    return sign * (1 - std::sqrt(s));
+}
+inline V2 squareToTent(V2 s) { return V2{ intervalToTent(s.x), intervalToTent(s.y) }; }
+
+/* ---- erf / erfinv (libcore/math.cpp:25-72) ------------------------------------------------ */
+inline Float erfinv(Float x) {
+    Float w = -std::log((1.0f - x) * (1.0f + x));
+    Float p;
+    if (w < 5.0f) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f;
+        p = 3.43273939e-07f + p * w;
+        p = -3.5233877e-06f + p * w;
+        p = -4.39150654e-06f + p * w;
+        p = 0.00021858087f + p * w;
+        p = -0.00125372503f + p * w;
+        p = -0.00417768164f + p * w;
+        p = 0.246640727f + p * w;
+        p = 1.50140941f + p * w;
+    } else {
+        w = std::sqrt(w) - 3.0f;
+        p = -0.000200214257f;
+        p = 0.000100950558f + p * w;
+        p = 0.00134934322f + p * w;
+        p = -0.00367342844f + p * w;
+        p = 0.00573950773f + p * w;
+        p = -0.0076224613f + p * w;
+        p = 0.00943887047f + p * w;
+        p = 1.00167406f + p * w;
+        p = 2.83297682f + p * w;
+    }
+    return p * x;
+}
+inline Float erf_as(Float x) {
+    const Float a1 = 0.254829592f, a2 = -0.284496736f, a3 = 1.421413741f, a4 = -1.453152027f,
+                a5 = 1.061405429f, p = 0.3275911f;
+    Float sign = signum(x);
+    x = std::fabs(x);
+    Float t = 1.0f / (1.0f + p * x);
+    Float y = 1.0f - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * std::exp(-x * x);
+    return sign * y;
+}
+
+/* ---- counter-based RNG (replaces samplers/independent.cpp + libcore/random.cpp) ------------ */
+struct Philox {
+    static inline void round(uint32_t c[4], const uint32_t k[2]) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+        uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    }
+    static inline void gen(uint32_t c[4], uint32_t k0, uint32_t k1) {
+        uint32_t k[2] = { k0, k1 };
+        for (int i = 0; i < 10; ++i) {
+            round(c, k);
+            k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+        }
+    }
+};
+/* libcore/random.cpp:630-639: 23 random mantissa bits -> [1,2) -> subtract 1 */
+inline Float u32ToFloat(uint32_t u) {
+    uint32_t bits = (u >> 9) | 0x3f800000u;
+    Float f; std::memcpy(&f, &bits, 4);
+    return f - 1.0f;
+}
+/* Sample stream of one camera sample: dimension d of (seed, pixel, sample).
+ * key = (pixel, seed_lo), counter = (sample, d/4, seed_hi, 0); element d%4. */
+struct SampleStream {
+    uint32_t pixel, sample, seedLo, seedHi;
+    uint32_t dim;
+    uint32_t cache[4]; int cachedBlock;
+    SampleStream(uint64_t seed, uint32_t pix, uint32_t smp)
+        : pixel(pix), sample(smp), seedLo((uint32_t)seed), seedHi((uint32_t)(seed >> 32)), dim(0), cachedBlock(-1) {}
+    Float next1D() {
+        int block = (int)(dim >> 2);
+        if (block != cachedBlock) {
+            cache[0] = sample; cache[1] = (uint32_t)block; cache[2] = seedHi; cache[3] = 0;
+            Philox::gen(cache, pixel, seedLo);
+            cachedBlock = block;
+        }
+        return u32ToFloat(cache[dim++ & 3]);
+    }
+    V2 next2D() { Float a = next1D(); Float b = next1D(); return V2{ a, b }; }
+};
+
+} /* namespace ora */
