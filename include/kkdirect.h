@@ -227,10 +227,12 @@ int kkd_scene_upload(kkd_ctx *ctx, const kkd_scene_desc *scene);
  * Film::setBitmap (src/films/hdrfilm.cpp:391-397).  stats may be NULL. */
 int kkd_render(kkd_ctx *ctx, const kkd_render_params *params, float *out_film, kkd_stats *stats);
 
-/* Same, but the film stays in device memory: *out_dev_film receives a device pointer owned by
- * the context (valid until the next render/destroy) so that multi-GPU callers can reduce it with
- * RCCL without a host round trip (sample-split mode). */
-int kkd_render_device(kkd_ctx *ctx, const kkd_render_params *params, void **out_dev_film, kkd_stats *stats);
+/* Same, but the film stays in device memory: dev_film is a caller-owned device buffer of
+ * crop_width*crop_height*5 floats (e.g. a torch tensor) that is overwritten with this call's sums, so
+ * that multi-GPU callers can reduce it with RCCL without a host round trip (sample-split mode,
+ * SURVEY 8e; the reduce plays the role of Film::put(block), src/films/hdrfilm.cpp:391-393).  The call
+ * returns after the work has completed on the context's own stream. */
+int kkd_render_device(kkd_ctx *ctx, const kkd_render_params *params, void *dev_film, kkd_stats *stats);
 
 /* Fixed-ray-set entry point: ShapeKDTree::rayIntersect(ray, its) when any_hit==0
  * (src/librender/skdtree.cpp:112-142) and ShapeKDTree::rayIntersect(ray) when any_hit!=0

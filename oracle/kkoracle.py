@@ -1,0 +1,211 @@
+"""ORACLE (test infrastructure only): ctypes loader for oracle/build/libkkoracle.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product (ray-tracer_amd/, libkkdirect.so) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_REPO = os.path.dirname(_HERE)
+sys.path.insert(0, os.path.join(_REPO, "ray-tracer_amd"))
+from kkdirect import abi  # noqa: E402  (struct layouts only)
+
+LIB_PATH = os.path.join(_HERE, "build", "libkkoracle.so")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        L.ora_create.restype = C.c_void_p
+        L.ora_create.argtypes = [C.POINTER(abi.SceneDesc), C.c_int]
+        L.ora_destroy.argtypes = [C.c_void_p]
+        L.ora_trace.argtypes = [C.c_void_p, abi.pf32, C.c_uint64, C.c_int, C.c_int, C.POINTER(abi.Hit), C.POINTER(C.c_uint64)]
+        L.ora_intersect_record.argtypes = [C.c_void_p, abi.pf32, abi.pf32]
+        L.ora_render.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_uint64, C.c_int, abi.pf32, C.POINTER(abi.Stats)]
+        L.ora_li_samples.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_uint64, abi.pu32, C.c_uint64, abi.pf32]
+        L.ora_camera_rays.argtypes = [C.c_void_p, abi.pf32, C.c_uint64, abi.pf32]
+        L.ora_philox.argtypes = [abi.pu32, abi.pu32, abi.pu32]
+        L.ora_sample_stream.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, abi.pf32]
+        L.ora_clip_aabb.argtypes = [abi.pf32, abi.pf32, abi.pf32]
+        L.ora_bsdf_eval.argtypes = [C.c_void_p, C.c_int, abi.pf32, abi.pf32, abi.pf32, abi.pf32]
+        L.ora_bsdf_sample.argtypes = [C.c_void_p, C.c_int, abi.pf32, abi.pf32, C.c_uint64, abi.pf32]
+        L.ora_bsdf_type.restype = C.c_uint32
+        L.ora_bsdf_type.argtypes = [C.c_void_p, C.c_int]
+        L.ora_microfacet_sample.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int, abi.pf32, abi.pf32, C.c_uint64, abi.pf32]
+        L.ora_microfacet_eval.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int, abi.pf32, abi.pf32, C.c_uint64, abi.pf32]
+        L.ora_rough_transmittance.argtypes = [C.c_int, C.c_float, C.c_float, abi.pf32, abi.pf32]
+        L.ora_rough_transmittance_at.restype = C.c_double
+        L.ora_rough_transmittance_at.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double]
+        L.ora_rfilter_table.argtypes = [C.c_int, C.c_float, abi.pf32, abi.pf32, abi.pf32, C.POINTER(C.c_int)]
+        L.ora_sample_emitter_direct.argtypes = [C.c_void_p, abi.pf32, abi.pf32, abi.pf32, C.c_uint64, abi.pf32]
+        L.ora_env_probe.argtypes = [C.c_void_p, abi.pf32, C.c_uint64, abi.pf32]
+        L.ora_kd_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(abi.pf32)
+
+
+HIT_DTYPE = np.dtype([("t", np.float32), ("u", np.float32), ("v", np.float32), ("prim", np.uint32)])
+
+
+class Oracle:
+    """CPU restatement of ShapeKDTree + kk DirectIntegrator for one scene."""
+
+    def __init__(self, scene, brute_force=False):
+        self.scene = scene
+        self._desc = scene.desc()
+        self.h = lib().ora_create(C.byref(self._desc), int(brute_force))
+        if not self.h:
+            raise RuntimeError("oracle: scene rejected")
+        s = self._desc.sensor
+        self.width, self.height = s.crop_width, s.crop_height
+
+    def close(self):
+        if self.h:
+            lib().ora_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def trace(self, rays, any_hit=False, brute=False, counts=False):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        out = np.zeros(len(rays), HIT_DTYPE)
+        cnt = (C.c_uint64 * 2)()
+        lib().ora_trace(self.h, _fp(rays), len(rays), int(any_hit), int(brute), out.ctypes.data_as(C.POINTER(abi.Hit)), cnt)
+        return (out, (cnt[0], cnt[1])) if counts else out
+
+    def intersect_record(self, ray):
+        ray = np.ascontiguousarray(ray, np.float32).reshape(8)
+        out = np.zeros(21, np.float32)
+        ok = lib().ora_intersect_record(self.h, _fp(ray), _fp(out))
+        if not ok:
+            return None
+        return dict(p=out[0:3], uv=out[3:5], geoN=out[5:8], shN=out[8:11], dpdu=out[11:14], dpdv=out[14:17], wi=out[17:20], t=out[20])
+
+    def camera_rays(self, sample_pos):
+        sp = np.ascontiguousarray(sample_pos, np.float32).reshape(-1, 2)
+        rays = np.zeros((len(sp), 8), np.float32)
+        lib().ora_camera_rays(self.h, _fp(sp), len(sp), _fp(rays))
+        return rays
+
+    def render(self, spp, bsdf_samples=1, light_samples=1, hide_emitters=False, seed=1, threads=None, block_size=0,
+               tile_index=0, tile_count=1, sample_first=0):
+        p = abi.RenderParams(spp, bsdf_samples, light_samples, int(hide_emitters), block_size, tile_index, tile_count, sample_first)
+        film = np.zeros((self.height, self.width, 5), np.float32)
+        st = abi.Stats()
+        rc = lib().ora_render(self.h, C.byref(p), seed, threads or os.cpu_count() or 1, _fp(film), C.byref(st))
+        if rc != 0:
+            raise RuntimeError("oracle render failed: %d" % rc)
+        return film, st
+
+    def li_samples(self, pix, bsdf_samples=1, light_samples=1, hide_emitters=False, seed=1):
+        """pix: n x (x, y, sampleIndex) -> n x (r, g, b, alpha, sx, sy)"""
+        pix = np.ascontiguousarray(pix, np.uint32).reshape(-1, 3)
+        p = abi.RenderParams(1, bsdf_samples, light_samples, int(hide_emitters), 0, 0, 1, 0)
+        out = np.zeros((len(pix), 6), np.float32)
+        lib().ora_li_samples(self.h, C.byref(p), seed, pix.ctypes.data_as(abi.pu32), len(pix), _fp(out))
+        return out
+
+    def bsdf_eval(self, mat, wi, wo):
+        wi = np.ascontiguousarray(wi, np.float32); wo = np.ascontiguousarray(wo, np.float32)
+        f = np.zeros(3, np.float32); pdf = np.zeros(1, np.float32)
+        lib().ora_bsdf_eval(self.h, mat, _fp(wi), _fp(wo), _fp(f), _fp(pdf))
+        return f, float(pdf[0])
+
+    def bsdf_sample(self, mat, wi, u2):
+        wi = np.ascontiguousarray(wi, np.float32); u2 = np.ascontiguousarray(u2, np.float32).reshape(-1, 2)
+        out = np.zeros((len(u2), 8), np.float32)
+        lib().ora_bsdf_sample(self.h, mat, _fp(wi), _fp(u2), len(u2), _fp(out))
+        return out
+
+    def bsdf_type(self, mat):
+        return lib().ora_bsdf_type(self.h, mat)
+
+    def sample_emitter_direct(self, ref, ref_n, u2):
+        ref = np.ascontiguousarray(ref, np.float32); ref_n = np.ascontiguousarray(ref_n, np.float32)
+        u2 = np.ascontiguousarray(u2, np.float32).reshape(-1, 2)
+        out = np.zeros((len(u2), 9), np.float32)
+        lib().ora_sample_emitter_direct(self.h, _fp(ref), _fp(ref_n), _fp(u2), len(u2), _fp(out))
+        return out
+
+    def env_probe(self, dirs):
+        dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        out = np.zeros((len(dirs), 4), np.float32)
+        lib().ora_env_probe(self.h, _fp(dirs), len(dirs), _fp(out))
+        return out
+
+    def kd_info(self):
+        a, b, d = C.c_uint64(), C.c_uint64(), C.c_int()
+        lib().ora_kd_info(self.h, C.byref(a), C.byref(b), C.byref(d))
+        return a.value, b.value, d.value
+
+
+def philox(ctr, key):
+    ctr = np.ascontiguousarray(ctr, np.uint32); key = np.ascontiguousarray(key, np.uint32)
+    out = np.zeros(4, np.uint32)
+    lib().ora_philox(ctr.ctypes.data_as(abi.pu32), key.ctypes.data_as(abi.pu32), out.ctypes.data_as(abi.pu32))
+    return out
+
+
+def sample_stream(seed, pixel, sample, n):
+    out = np.zeros(n, np.float32)
+    lib().ora_sample_stream(seed, pixel, sample, n, _fp(out))
+    return out
+
+
+def clip_aabb(tri, box):
+    tri = np.ascontiguousarray(tri, np.float32).reshape(9); box = np.ascontiguousarray(box, np.float32).reshape(6)
+    out = np.zeros(6, np.float32)
+    lib().ora_clip_aabb(_fp(tri), _fp(box), _fp(out))
+    return out.reshape(2, 3)
+
+
+def microfacet_sample(distr, au, av, visible, wi, u2):
+    wi = np.ascontiguousarray(wi, np.float32); u2 = np.ascontiguousarray(u2, np.float32).reshape(-1, 2)
+    out = np.zeros((len(u2), 4), np.float32)
+    lib().ora_microfacet_sample(distr, au, av, int(visible), _fp(wi), _fp(u2), len(u2), _fp(out))
+    return out
+
+
+def microfacet_eval(distr, au, av, visible, wi, m):
+    wi = np.ascontiguousarray(wi, np.float32); m = np.ascontiguousarray(m, np.float32).reshape(-1, 3)
+    out = np.zeros((len(m), 3), np.float32)
+    lib().ora_microfacet_eval(distr, au, av, int(visible), _fp(wi), _fp(m), len(m), _fp(out))
+    return out
+
+
+def rough_transmittance(distr, alpha, eta):
+    t = np.zeros(100, np.float32); d = np.zeros(1, np.float32)
+    lib().ora_rough_transmittance(distr, alpha, eta, _fp(t), _fp(d))
+    return t, float(d[0])
+
+
+def rough_transmittance_at(distr, alpha, eta, cos_theta):
+    return lib().ora_rough_transmittance_at(distr, alpha, eta, cos_theta)
+
+
+def rfilter_table(ftype, radius, param=(0.5, 0.0)):
+    p = np.asarray(param, np.float32); v = np.zeros(32, np.float32); s = np.zeros(1, np.float32); b = C.c_int()
+    lib().ora_rfilter_table(ftype, radius, _fp(p), _fp(v), _fp(s), C.byref(b))
+    return v, float(s[0]), b.value

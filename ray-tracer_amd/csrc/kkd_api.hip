@@ -1,0 +1,348 @@
+/*
+ * kkd_api.hip -- the C ABI of libkkdirect.so (include/kkdirect.h): context, scene upload, render loop,
+ * fixed-ray-set tracing.  Host orchestration only; all per-sample work is in kkd_kernels.hip.
+ *
+ * Replaces, for the kk direct path, SamplingIntegrator::render + BlockedRenderProcess + BlockRenderer
+ * (reference src/librender/integrator.cpp:95-129, src/librender/renderproc.cpp:26-184): instead of a
+ * work queue of 32x32 RectangularWorkUnits pulled by one thread per core, the tiles assigned to this
+ * context are walked in batches of camera samples, each batch being five kernel launches on one stream.
+ */
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "kkd_host.h"
+#include "kkd_kernels.h"
+
+using namespace kkd;
+
+namespace {
+
+std::string g_createError = "";
+
+struct DevBuf {
+    void *p = nullptr; size_t bytes = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= bytes) return hipSuccess;
+        if (p) { hipFree(p); p = nullptr; bytes = 0; }
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    void release() { if (p) hipFree(p); p = nullptr; bytes = 0; }
+};
+
+} /* namespace */
+
+struct kkd_ctx {
+    int device = 0;
+    kkd_config cfg{};
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::atomic<int> cancel{0};
+    bool haveScene = false;
+    int stackClass = 0;
+    HostScene hs;
+    DScene ds{};
+    /* scene buffers */
+    DevBuf nodes, tris, positions, normals, texcoords, indices, shapes, materials, emitters, emitterCdf, areaCdf, rtTables,
+           envTexels, envCdfRows, envCdfCols, envRowWeights;
+    /* work buffers */
+    DevBuf hits, accum, refN, bsdfRays, bsdfHits, brec0, shadowRays, occluded, lrec, film, counters, apiRays, apiHits;
+    std::vector<hipEvent_t> events;
+};
+
+#define KKD_HIP(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return KKD_ERR_DEVICE; } } while (0)
+
+static int fail(kkd_ctx *ctx, int code, const std::string &msg) { ctx->err = msg; return code; }
+
+template <typename T> static int upload(kkd_ctx *ctx, DevBuf &buf, const T *src, size_t count) {
+    const size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    hipError_t e = buf.ensure(bytes);
+    if (e != hipSuccess) { ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e); return e == hipErrorOutOfMemory ? KKD_ERR_NOMEM : KKD_ERR_DEVICE; }
+    if (count) KKD_HIP(ctx, hipMemcpyAsync(buf.p, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return KKD_OK;
+}
+
+extern "C" {
+
+int kkd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+kkd_ctx *kkd_create(const kkd_config *cfg) {
+    if (!cfg) { g_createError = "kkd_create: config is NULL"; return nullptr; }
+    int n = kkd_device_count();
+    if (n <= 0) { g_createError = "kkd_create: no HIP device available (libkkdirect has no CPU fallback)"; return nullptr; }
+    if (cfg->device < 0 || cfg->device >= n) { g_createError = "kkd_create: device ordinal out of range"; return nullptr; }
+    hipError_t e = hipSetDevice(cfg->device);
+    if (e != hipSuccess) { g_createError = std::string("hipSetDevice: ") + hipGetErrorString(e); return nullptr; }
+    kkd_ctx *ctx = new kkd_ctx();
+    ctx->device = cfg->device; ctx->cfg = *cfg;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { g_createError = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete ctx; return nullptr; }
+    g_createError = "";
+    return ctx;
+}
+
+const char *kkd_last_error(kkd_ctx *ctx) { return ctx ? ctx->err.c_str() : g_createError.c_str(); }
+
+void kkd_request_cancel(kkd_ctx *ctx) { if (ctx) ctx->cancel.store(1); }
+
+void kkd_destroy(kkd_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    DevBuf *all[] = { &ctx->nodes, &ctx->tris, &ctx->positions, &ctx->normals, &ctx->texcoords, &ctx->indices, &ctx->shapes, &ctx->materials,
+                      &ctx->emitters, &ctx->emitterCdf, &ctx->areaCdf, &ctx->rtTables, &ctx->envTexels, &ctx->envCdfRows, &ctx->envCdfCols,
+                      &ctx->envRowWeights, &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->shadowRays,
+                      &ctx->occluded, &ctx->lrec, &ctx->film, &ctx->counters, &ctx->apiRays, &ctx->apiHits };
+    for (DevBuf *b : all) b->release();
+    for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int kkd_scene_upload(kkd_ctx *ctx, const kkd_scene_desc *sd) {
+    if (!ctx) return KKD_ERR_INVALID;
+    ctx->haveScene = false;
+    int code = KKD_ERR_INVALID;
+    if (!flattenScene(sd, ctx->hs, ctx->err, &code)) return code;
+    HostScene &hs = ctx->hs;
+    if (hs.bvh.info.maxStack <= 32) ctx->stackClass = 0;
+    else if (hs.bvh.info.maxStack <= 96) ctx->stackClass = 1;
+    else return fail(ctx, KKD_ERR_UNSUPPORTED, "acceleration structure deeper than the 96-entry traversal stack");
+    KKD_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+#define UP(buf, ptr, n) if ((rc = upload(ctx, ctx->buf, ptr, n)) != KKD_OK) return rc;
+    UP(nodes, hs.bvh.nodes.data(), hs.bvh.nodes.size())
+    UP(tris, hs.bvh.tris.data(), hs.bvh.tris.size())
+    UP(positions, sd->positions, 3 * (size_t)sd->n_verts)
+    UP(normals, sd->normals, sd->normals ? 3 * (size_t)sd->n_verts : 0)
+    UP(texcoords, sd->texcoords, sd->texcoords ? 2 * (size_t)sd->n_verts : 0)
+    UP(indices, sd->indices, 3 * (size_t)sd->n_tris)
+    UP(shapes, hs.shapes.data(), hs.shapes.size())
+    UP(materials, hs.materials.data(), hs.materials.size())
+    UP(emitters, hs.emitters.data(), hs.emitters.size())
+    UP(emitterCdf, hs.emitterCdf.data(), hs.emitterCdf.size())
+    UP(areaCdf, hs.areaCdf.data(), hs.areaCdf.size())
+    UP(rtTables, hs.rtTables.data(), hs.rtTables.size())
+    UP(envTexels, hs.envTexels.data(), hs.envTexels.size())
+    UP(envCdfRows, hs.envCdfRows.data(), hs.envCdfRows.size())
+    UP(envCdfCols, hs.envCdfCols.data(), hs.envCdfCols.size())
+    UP(envRowWeights, hs.envRowWeights.data(), hs.envRowWeights.size())
+#undef UP
+    KKD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DScene &d = ctx->ds;
+    std::memset(&d, 0, sizeof(d));
+    d.nodes = (const Node4 *)ctx->nodes.p; d.tris = (const LeafTri *)ctx->tris.p;
+    d.positions = (const float *)ctx->positions.p; d.normals = (const float *)ctx->normals.p; d.texcoords = (const float *)ctx->texcoords.p;
+    d.indices = (const uint32_t *)ctx->indices.p;
+    d.shapes = (const DShape *)ctx->shapes.p; d.materials = (const DMaterial *)ctx->materials.p; d.emitters = (const DEmitter *)ctx->emitters.p;
+    d.emitterCdf = (const float *)ctx->emitterCdf.p; d.areaCdf = (const float *)ctx->areaCdf.p; d.rtTables = (const float *)ctx->rtTables.p;
+    d.nShapes = (uint32_t)hs.shapes.size(); d.nMaterials = (uint32_t)hs.materials.size(); d.nEmitters = (uint32_t)hs.emitters.size();
+    d.envEmitter = hs.envEmitter; d.emitterNormalization = hs.emitterNormalization;
+    d.env = hs.env;
+    d.env.texels = (const uint32_t *)ctx->envTexels.p; d.env.cdfRows = (const float *)ctx->envCdfRows.p;
+    d.env.cdfCols = (const float *)ctx->envCdfCols.p; d.env.rowWeights = (const float *)ctx->envRowWeights.p;
+    d.sensor = hs.sensor; d.filter = hs.filter;
+    /* host copies that are only needed for the upload */
+    std::vector<uint16_t>().swap(hs.envTexels); std::vector<float>().swap(hs.envCdfCols);
+    ctx->haveScene = true;
+    ctx->err.clear();
+    return KKD_OK;
+}
+
+int kkd_accel_info(kkd_ctx *ctx, uint32_t *node_bytes, uint32_t *tri_bytes, uint64_t *n_nodes, uint64_t *n_leaf_tris) {
+    if (!ctx) return KKD_ERR_INVALID;
+    if (!ctx->haveScene) return fail(ctx, KKD_ERR_INVALID, "no scene uploaded");
+    if (node_bytes) *node_bytes = (uint32_t)sizeof(Node4);
+    if (tri_bytes) *tri_bytes = (uint32_t)sizeof(LeafTri);
+    if (n_nodes) *n_nodes = ctx->hs.bvh.info.nNodes;
+    if (n_leaf_tris) *n_leaf_tris = ctx->hs.bvh.info.nLeafTris;
+    return KKD_OK;
+}
+
+/* ---- fixed ray sets ---- */
+static int traceImpl(kkd_ctx *ctx, const void *devRays, uint64_t n, int anyHit, void *devOut, bool count, kkd_stats *stats) {
+    if (!ctx->haveScene) return fail(ctx, KKD_ERR_INVALID, "no scene uploaded");
+    KKD_HIP(ctx, hipSetDevice(ctx->device));
+    KKD_HIP(ctx, ctx->counters.ensure(sizeof(DeviceCounters)));
+    KKD_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, sizeof(DeviceCounters), ctx->stream));
+    hipEvent_t e0, e1;
+    KKD_HIP(ctx, hipEventCreate(&e0)); KKD_HIP(ctx, hipEventCreate(&e1));
+    KKD_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    const uint64_t chunk = 1ull << 30;   /* keep grid sizes within 32 bits */
+    for (uint64_t off = 0; off < n; off += chunk) {
+        const uint64_t m = std::min(chunk, n - off);
+        launchTrace(ctx->stream, ctx->stackClass, ctx->ds, (const DRay *)devRays + off, m, anyHit != 0, count, 1, (DHit *)devOut + off, (DeviceCounters *)ctx->counters.p);
+    }
+    KKD_HIP(ctx, hipGetLastError());
+    KKD_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    DeviceCounters c;
+    KKD_HIP(ctx, hipMemcpyAsync(&c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+    KKD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    KKD_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->rays_closest = c.raysClosest; stats->rays_shadow = c.raysShadow;
+        stats->seconds = stats->seconds_trace = ms * 1e-3;
+        stats->nodes_visited = c.nodes; stats->tris_tested = c.tris;
+        const double rays = (double)(c.raysClosest + c.raysShadow);
+        stats->algorithmic_bytes = rays * 48.0 + (count ? (double)c.nodes * sizeof(Node4) + (double)c.tris * sizeof(LeafTri) : 0.0);
+    }
+    return KKD_OK;
+}
+
+int kkd_trace_device(kkd_ctx *ctx, const void *dev_rays, uint64_t n, int any_hit, void *dev_out, kkd_stats *stats) {
+    if (!ctx) return KKD_ERR_INVALID;
+    if (n && (!dev_rays || !dev_out)) return fail(ctx, KKD_ERR_INVALID, "kkd_trace_device: NULL buffer");
+    return traceImpl(ctx, dev_rays, n, any_hit, dev_out, false, stats);
+}
+
+static int traceHost(kkd_ctx *ctx, const float *rays, uint64_t n, int anyHit, kkd_hit *out, bool count, kkd_stats *stats) {
+    if (!ctx) return KKD_ERR_INVALID;
+    if (n && (!rays || !out)) return fail(ctx, KKD_ERR_INVALID, "kkd_trace: NULL buffer");
+    if (!ctx->haveScene) return fail(ctx, KKD_ERR_INVALID, "no scene uploaded");
+    if (n == 0) { if (stats) std::memset(stats, 0, sizeof(*stats)); return KKD_OK; }
+    KKD_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = ctx->apiRays.ensure(n * sizeof(DRay));
+    if (e == hipSuccess) e = ctx->apiHits.ensure(n * sizeof(DHit));
+    if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? KKD_ERR_NOMEM : KKD_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+    KKD_HIP(ctx, hipMemcpyAsync(ctx->apiRays.p, rays, n * sizeof(DRay), hipMemcpyHostToDevice, ctx->stream));
+    int rc = traceImpl(ctx, ctx->apiRays.p, n, anyHit, ctx->apiHits.p, count, stats);
+    if (rc != KKD_OK) return rc;
+    KKD_HIP(ctx, hipMemcpy(out, ctx->apiHits.p, n * sizeof(DHit), hipMemcpyDeviceToHost));
+    return KKD_OK;
+}
+
+int kkd_trace(kkd_ctx *ctx, const float *rays, uint64_t n, int any_hit, kkd_hit *out) { return traceHost(ctx, rays, n, any_hit, out, false, nullptr); }
+int kkd_trace_counted(kkd_ctx *ctx, const float *rays, uint64_t n, int any_hit, kkd_hit *out, kkd_stats *stats) { return traceHost(ctx, rays, n, any_hit, out, true, stats); }
+
+/* ---- render ---- */
+static uint32_t pow2ceil(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
+
+static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm, kkd_stats *stats) {
+    if (!ctx->haveScene) return fail(ctx, KKD_ERR_INVALID, "no scene uploaded");
+    if (!rp) return fail(ctx, KKD_ERR_INVALID, "render params are NULL");
+    if (rp->spp == 0) return fail(ctx, KKD_ERR_INVALID, "spp must be positive");
+    /* kk/direct.cpp:165-166 divides by both counts: zero is not a meaningful configuration */
+    if (rp->bsdf_samples == 0 || rp->light_samples == 0) return fail(ctx, KKD_ERR_UNSUPPORTED, "bsdfSamples and lightSamples must be >= 1");
+    if (rp->bsdf_samples > 64 || rp->light_samples > 64) return fail(ctx, KKD_ERR_UNSUPPORTED, "bsdfSamples / lightSamples above 64");
+    const uint32_t bs = rp->block_size ? rp->block_size : 32;                    /* scene.cpp:24 */
+    if (bs < 2 || bs > 128) return fail(ctx, KKD_ERR_INVALID, "block size must be in [2, 128]");   /* mitsuba.cpp:142 */
+    if ((int)bs < ctx->ds.filter.border) return fail(ctx, KKD_ERR_INVALID, "block size must be >= the filter border");   /* renderproc.cpp:173-174 */
+    const uint32_t tileCount = rp->tile_count ? rp->tile_count : 1, tileIndex = rp->tile_count ? rp->tile_index : 0;
+    if (tileIndex >= tileCount) return fail(ctx, KKD_ERR_INVALID, "tile_index must be < tile_count");
+    KKD_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->cancel.store(0);
+
+    const int W = ctx->ds.sensor.cropW, H = ctx->ds.sensor.cropH;
+    const uint32_t nbx = (W + bs - 1) / bs, nby = (H + bs - 1) / bs, nTiles = nbx * nby;
+    const uint32_t nTilesMine = tileIndex < nTiles ? (nTiles - tileIndex + tileCount - 1) / tileCount : 0;
+    const uint32_t g = std::min(64u, pow2ceil(rp->spp)), chunks = (rp->spp + g - 1) / g;
+    uint32_t gShift = 0; while ((1u << gShift) < g) ++gShift;
+    const uint64_t total = (uint64_t)nTilesMine * bs * bs * chunks * g;
+    uint64_t batch = ctx->cfg.max_samples_in_flight ? ctx->cfg.max_samples_in_flight : (1ull << 21);
+    batch = std::max<uint64_t>(256, (batch + 255) / 256 * 256);
+    batch = std::min<uint64_t>(batch, 1ull << 28);
+    batch = std::min<uint64_t>(batch, std::max<uint64_t>(256, (total + 255) / 256 * 256));
+    const uint32_t nB = rp->bsdf_samples, nL = rp->light_samples;
+    const size_t S = (size_t)batch;
+
+    hipError_t e = hipSuccess;
+    auto need = [&](DevBuf &b, size_t bytes) { if (e == hipSuccess) e = b.ensure(bytes); };
+    need(ctx->hits, S * sizeof(DHit)); need(ctx->accum, S * 16); need(ctx->refN, S * 16);
+    need(ctx->bsdfRays, S * nB * sizeof(DRay)); need(ctx->bsdfHits, S * nB * sizeof(DHit)); need(ctx->brec0, S * nB * 16);
+    need(ctx->shadowRays, S * nL * sizeof(DRay)); need(ctx->occluded, S * nL * 4); need(ctx->lrec, S * nL * 16);
+    need(ctx->counters, sizeof(DeviceCounters));
+    if (!devFilm) need(ctx->film, (size_t)W * H * 5 * sizeof(float));
+    if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? KKD_ERR_NOMEM : KKD_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+    float *film = devFilm ? devFilm : (float *)ctx->film.p;
+
+    WaveBuffers wb;
+    wb.hits = (DHit *)ctx->hits.p; wb.accum = (float4 *)ctx->accum.p; wb.refN = (float4 *)ctx->refN.p;
+    wb.bsdfRays = (DRay *)ctx->bsdfRays.p; wb.bsdfHits = (DHit *)ctx->bsdfHits.p; wb.brec0 = (float4 *)ctx->brec0.p;
+    wb.shadowRays = (DRay *)ctx->shadowRays.p; wb.occluded = (uint32_t *)ctx->occluded.p; wb.lrec = (float4 *)ctx->lrec.p;
+    DeviceCounters *ctr = (DeviceCounters *)ctx->counters.p;
+
+    BatchParams bp;
+    std::memset(&bp, 0, sizeof(bp));
+    bp.seed = ctx->cfg.seed; bp.stride = (uint32_t)S;
+    bp.g = g; bp.gShift = gShift; bp.chunks = chunks; bp.spp = rp->spp; bp.sampleFirst = rp->sample_first;
+    bp.nB = nB; bp.nL = nL; bp.hideEmitters = rp->hide_emitters != 0;
+    bp.bs = bs; bp.bsPow2 = (bs & (bs - 1)) == 0; bp.nbx = nbx; bp.nby = nby;
+    bp.tileIndex = tileIndex; bp.tileCount = tileCount; bp.nTilesMine = nTilesMine; bp.W = W; bp.H = H;
+
+    const uint64_t nBatches = (total + batch - 1) / batch;
+    const bool timeTrace = stats != nullptr && nBatches <= 4096;
+    const size_t nEvents = 2 + (timeTrace ? (size_t)nBatches * 2 * 3 : 0);
+    while (ctx->events.size() < nEvents) { hipEvent_t ev; KKD_HIP(ctx, hipEventCreate(&ev)); ctx->events.push_back(ev); }
+
+    hipStream_t st = ctx->stream;
+    KKD_HIP(ctx, hipMemsetAsync(film, 0, (size_t)W * H * 5 * sizeof(float), st));
+    KKD_HIP(ctx, hipMemsetAsync(ctr, 0, sizeof(DeviceCounters), st));
+    KKD_HIP(ctx, hipEventRecord(ctx->events[0], st));
+    size_t ev = 2;
+    bool cancelled = false;
+    for (uint64_t w0 = 0; w0 < total; w0 += batch) {
+        if (ctx->cancel.load()) { cancelled = true; break; }
+        bp.w0 = w0; bp.count = (uint32_t)std::min<uint64_t>(batch, total - w0);
+        if (timeTrace) hipEventRecord(ctx->events[ev++], st);
+        launchPrimary(st, ctx->stackClass, ctx->ds, bp, wb.hits, ctr);
+        if (timeTrace) hipEventRecord(ctx->events[ev++], st);
+        launchShade(st, ctx->ds, bp, wb);
+        if (timeTrace) hipEventRecord(ctx->events[ev++], st);
+        /* all nB planes are contiguous when count == stride; otherwise trace plane by plane */
+        if (bp.count == bp.stride) launchTrace(st, ctx->stackClass, ctx->ds, wb.bsdfRays, (uint64_t)S * nB, false, false, 0, wb.bsdfHits, ctr);
+        else for (uint32_t b = 0; b < nB; ++b) launchTrace(st, ctx->stackClass, ctx->ds, wb.bsdfRays + (size_t)b * S, bp.count, false, false, 0, wb.bsdfHits + (size_t)b * S, ctr);
+        if (timeTrace) { hipEventRecord(ctx->events[ev++], st); hipEventRecord(ctx->events[ev++], st); }
+        if (bp.count == bp.stride) launchTrace(st, ctx->stackClass, ctx->ds, wb.shadowRays, (uint64_t)S * nL, true, false, 2, wb.occluded, ctr);
+        else for (uint32_t l = 0; l < nL; ++l) launchTrace(st, ctx->stackClass, ctx->ds, wb.shadowRays + (size_t)l * S, bp.count, true, false, 2, wb.occluded + (size_t)l * S, ctr);
+        if (timeTrace) hipEventRecord(ctx->events[ev++], st);
+        launchResolve(st, ctx->ds, bp, wb, film, ctr);
+    }
+    KKD_HIP(ctx, hipGetLastError());
+    KKD_HIP(ctx, hipEventRecord(ctx->events[1], st));
+    DeviceCounters c;
+    KKD_HIP(ctx, hipMemcpyAsync(&c, ctr, sizeof(c), hipMemcpyDeviceToHost, st));
+    KKD_HIP(ctx, hipStreamSynchronize(st));
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        float ms = 0.f;
+        KKD_HIP(ctx, hipEventElapsedTime(&ms, ctx->events[0], ctx->events[1]));
+        stats->samples = c.samples; stats->rays_closest = c.raysClosest; stats->rays_shadow = c.raysShadow;
+        stats->seconds = ms * 1e-3;
+        double traceMs = 0.0;
+        if (timeTrace) for (size_t k = 2; k + 1 < ev; k += 2) { float t = 0.f; if (hipEventElapsedTime(&t, ctx->events[k], ctx->events[k + 1]) == hipSuccess) traceMs += t; }
+        stats->seconds_trace = traceMs * 1e-3;
+    }
+    if (cancelled) return fail(ctx, KKD_ERR_CANCELLED, "render cancelled");
+    return KKD_OK;
+}
+
+int kkd_render_device(kkd_ctx *ctx, const kkd_render_params *params, void *dev_film, kkd_stats *stats) {
+    if (!ctx) return KKD_ERR_INVALID;
+    if (!dev_film) return fail(ctx, KKD_ERR_INVALID, "kkd_render_device: film buffer is NULL");
+    return renderImpl(ctx, params, (float *)dev_film, stats);
+}
+
+int kkd_render(kkd_ctx *ctx, const kkd_render_params *params, float *out_film, kkd_stats *stats) {
+    if (!ctx) return KKD_ERR_INVALID;
+    if (!out_film) return fail(ctx, KKD_ERR_INVALID, "kkd_render: film buffer is NULL");
+    int rc = renderImpl(ctx, params, nullptr, stats);
+    if (rc != KKD_OK && rc != KKD_ERR_CANCELLED) return rc;
+    const size_t bytes = (size_t)ctx->ds.sensor.cropW * ctx->ds.sensor.cropH * 5 * sizeof(float);
+    hipError_t e = hipMemcpy(out_film, ctx->film.p, bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(ctx, KKD_ERR_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e));
+    return rc;
+}
+
+} /* extern "C" */

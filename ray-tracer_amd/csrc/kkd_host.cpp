@@ -1,0 +1,488 @@
+/*
+ * kkd_host.cpp -- scene flattening and table construction on the host (runs once per scene upload).
+ *
+ * What each part replaces in the reference (paths relative to /root/reference/src):
+ *   shape map / global primitive ids      librender/skdtree.cpp:49-70
+ *   emitter PDF                            librender/scene.cpp:376-380 (+ pmf.h DiscreteDistribution)
+ *   triangle area CDF                      librender/trimesh.cpp:392-407, libcore/triangle.cpp:61-67
+ *   BSDF configure()                       bsdfs/diffuse.cpp:93-104, roughconductor.cpp:228-250,
+ *                                          roughplastic.cpp:255-307, dielectric.cpp:184-202, twosided.cpp:84-106,
+ *                                          librender/bsdf.cpp:105-130 (ensureEnergyConservation)
+ *   rough transmittance                    bsdfs/rtrans.h:183-280 (the data/microfacet/*.dat file it reads is absent
+ *                                          from the reference tree; the table is integrated here from its definition,
+ *                                          utils/rdielprec.cpp:40-112 + bsdfs/roughdielectric.cpp:424-511)
+ *   EnvironmentMap::configure              emitters/envmap.cpp:260-329 (marginal / conditional CDF)
+ *   perspective sensor                     sensors/perspective.cpp:126-163, librender/sensor.cpp:101-107
+ *   reconstruction filter table            libcore/rfilter.cpp:37-55, rfilters/*.cpp
+ */
+#include "kkd_host.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
+
+namespace kkd {
+
+/* ---- half conversion (round to nearest even), as OpenEXR's half used by TMIPMap<Spectrum, SpectrumHalf> ---- */
+uint16_t floatToHalf(float f) {
+    uint32_t x; std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u, e8 = (x >> 23) & 0xFFu;
+    uint32_t mant = x & 0x7FFFFFu;
+    if (e8 == 0xFF) return (uint16_t)(sign | 0x7C00u | (mant ? 0x200u : 0u));
+    const int32_t e = (int32_t)e8 - 112;
+    if (e >= 31) return (uint16_t)(sign | 0x7C00u);
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;
+        mant |= 0x800000u;
+        const int shift = 14 - e;
+        uint32_t h = mant >> shift;
+        const uint32_t rem = mant & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (h & 1u))) ++h;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = ((uint32_t)e << 10) | (mant >> 13);
+    const uint32_t rem = mant & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
+    return (uint16_t)(sign | h);
+}
+float halfToFloat(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1Fu;
+    uint32_t mant = h & 0x3FFu, x;
+    if (e == 0) {
+        if (!mant) x = sign;
+        else {
+            int sh = 0;
+            while (!(mant & 0x400u)) { mant <<= 1; ++sh; }
+            x = sign | ((uint32_t)(113 - sh) << 23) | ((mant & 0x3FFu) << 13);
+        }
+    } else if (e == 31) x = sign | 0x7F800000u | (mant << 13);
+    else x = sign | ((e + 112u) << 23) | (mant << 13);
+    float f; std::memcpy(&f, &x, 4); return f;
+}
+
+/* ---- reconstruction filter (libcore/rfilter.cpp:37-55) ---- */
+static float filterEval(int type, float radius, const float *param, float x) {
+    auto cubic = [](float x, float B, float C) {
+        x = std::fabs(x);
+        const float x2 = x * x, x3 = x2 * x;
+        if (x < 1) return 1.0f / 6.0f * ((12 - 9 * B - 6 * C) * x3 + (-18 + 12 * B + 6 * C) * x2 + (6 - 2 * B));
+        if (x < 2) return 1.0f / 6.0f * ((-B - 6 * C) * x3 + (6 * B + 30 * C) * x2 + (-12 * B - 48 * C) * x + (8 * B + 24 * C));
+        return 0.0f;
+    };
+    switch (type) {
+        case KKD_RFILTER_GAUSSIAN: {   /* rfilters/gaussian.cpp:52-57 */
+            const float alpha = -1.0f / (2.0f * param[0] * param[0]);
+            return std::max(0.0f, std::exp(alpha * x * x) - std::exp(alpha * radius * radius));
+        }
+        case KKD_RFILTER_BOX: return std::fabs(x) <= radius ? 1.0f : 0.0f;            /* rfilters/box.cpp:44-46 */
+        case KKD_RFILTER_TENT: return std::max(0.0f, 1.0f - std::fabs(x / radius));   /* rfilters/tent.cpp */
+        case KKD_RFILTER_MITCHELL: return cubic(x, param[0], param[1]);               /* rfilters/mitchell.cpp */
+        case KKD_RFILTER_CATMULLROM: return cubic(x, 0.0f, 0.5f);                     /* rfilters/catmullrom.cpp */
+        case KKD_RFILTER_LANCZOS: {                                                   /* rfilters/lanczos.cpp */
+            x = std::fabs(x);
+            if (x < kEpsilon) return 1.0f;
+            if (x > radius) return 0.0f;
+            const float x1 = kPi * x, x2 = x1 / radius;
+            return (std::sin(x1) * std::sin(x2)) / (x1 * x2);
+        }
+    }
+    return 0.0f;
+}
+void configureFilter(int type, float radius, const float *param, DFilter &f) {
+    const int RES = 31;   /* MTS_FILTER_RESOLUTION */
+    float sum = 0.0f;
+    for (int i = 0; i < RES; ++i) { f.values[i] = filterEval(type, radius, param, (radius * i) / RES); sum += f.values[i]; }
+    f.values[RES] = 0.0f;
+    f.radius = radius; f.scaleFactor = RES / radius; f.border = (int)std::ceil(radius - 0.5f); f.pad = 0;
+    sum *= 2 * radius / RES;
+    const float normalization = 1.0f / sum;
+    for (int i = 0; i < RES; ++i) f.values[i] *= normalization;
+}
+
+/* ---- rough transmittance by quadrature over the microfacet-normal sampling square -------------------
+ * T(mu) = E_m[(1-F(wi.m)) G1(wo,m)] with m drawn from the visible-normal density
+ *       = int (1-F) G1(wo,m) G1(wi,m) |wi.m| D(m) / mu dm.
+ * Substituting the full-distribution warp (xi1 -> tan^2(theta_m), xi2 -> phi) turns D(m) cos(theta_m) dm
+ * into dxi1 dxi2, so T = int_0^1 int_0^1 (1-F) G1o G1i |wi.m| / (mu cos(theta_m)) dxi1 dxi2. */
+namespace {
+struct MF {
+    int type; double a;
+    double D(double mx, double my, double mz) const {
+        if (mz <= 0) return 0;
+        const double c2 = mz * mz, ex = (mx * mx + my * my) / (a * a) / c2;
+        double r;
+        if (type == KKD_DISTR_BECKMANN) r = std::exp(-ex) / (M_PI * a * a * c2 * c2);
+        else { const double root = (1 + ex) * c2; r = 1.0 / (M_PI * a * a * root * root); }
+        if (r * mz < 1e-20) r = 0;
+        return r;
+    }
+    /* bsdfs/microfacet.h:475-512 */
+    double G1(double vx, double vy, double vz, double mx, double my, double mz) const {
+        if ((vx * mx + vy * my + vz * mz) * vz <= 0) return 0;
+        const double s2 = 1 - vz * vz;
+        const double tanT = s2 <= 0 ? 0.0 : std::fabs(std::sqrt(s2) / vz);
+        if (tanT == 0) return 1;
+        if (type == KKD_DISTR_BECKMANN) {
+            const double x = 1.0 / (a * tanT);
+            if (x >= 1.6) return 1;
+            return (3.535 * x + 2.181 * x * x) / (1.0 + 2.276 * x + 2.577 * x * x);
+        }
+        const double root = a * tanT;
+        return 2.0 / (1.0 + std::sqrt(1.0 + root * root));
+    }
+};
+
+void gaussLegendre01(int n, std::vector<double> &x, std::vector<double> &w) {
+    x.resize(n); w.resize(n);
+    for (int i = 0; i < (n + 1) / 2; ++i) {
+        double z = std::cos(M_PI * (i + 0.75) / (n + 0.5)), pp = 1;
+        for (int it = 0; it < 64; ++it) {
+            double p1 = 1, p2 = 0;
+            for (int j = 0; j < n; ++j) { const double p3 = p2; p2 = p1; p1 = ((2.0 * j + 1) * z * p2 - j * p3) / (j + 1); }
+            pp = n * (z * p1 - p2) / (z * z - 1);
+            const double dz = p1 / pp; z -= dz;
+            if (std::fabs(dz) < 1e-15) break;
+        }
+        x[i] = 0.5 * (1 - z); x[n - 1 - i] = 0.5 * (1 + z);
+        w[i] = w[n - 1 - i] = 1.0 / ((1 - z * z) * pp * pp);
+    }
+}
+
+double transmittanceAt(const MF &d, double eta, double mu, const std::vector<double> &gx, const std::vector<double> &gw) {
+    const double wix = std::sqrt(std::max(0.0, 1 - mu * mu)), wiz = mu;
+    const int nPhi = 192;
+    double total = 0;
+    /* split xi1 at 0.9 so the GGX / Beckmann tails are resolved */
+    const double seg[4] = { 0.0, 0.9, 0.999, 1.0 };
+    for (int s = 0; s < 3; ++s) for (size_t i = 0; i < gx.size(); ++i) {
+        const double xi = seg[s] + (seg[s + 1] - seg[s]) * gx[i], wgt = (seg[s + 1] - seg[s]) * gw[i];
+        const double tan2 = d.type == KKD_DISTR_BECKMANN ? -d.a * d.a * std::log(1 - xi) : d.a * d.a * xi / (1 - xi);
+        const double cosT = 1.0 / std::sqrt(1 + tan2), sinT = std::sqrt(std::max(0.0, 1 - cosT * cosT));
+        double ring = 0;
+        for (int ip = 0; ip < nPhi; ++ip) {
+            const double phi = M_PI * (ip + 0.5) / nPhi;   /* half circle, mirrored */
+            const double mx = sinT * std::cos(phi), my = sinT * std::sin(phi), mz = cosT;
+            if (d.D(mx, my, mz) == 0) continue;
+            const double c = wix * mx + wiz * mz;
+            const double scale = c > 0 ? 1 / eta : eta, ct2 = 1 - (1 - c * c) * scale * scale;
+            if (ct2 <= 0) continue;                         /* total internal reflection */
+            const double ci = std::fabs(c), ct = std::sqrt(ct2);
+            const double Rs = (ci - eta * ct) / (ci + eta * ct), Rp = (eta * ci - ct) / (eta * ci + ct);
+            const double F = 0.5 * (Rs * Rs + Rp * Rp), cosTt = c > 0 ? -ct : ct;
+            const double e = cosTt < 0 ? 1 / eta : eta, k = c * e + cosTt;   /* refract(), libcore/util.cpp:741-747 */
+            const double wox = mx * k - wix * e, woy = my * k, woz = mz * k - wiz * e;
+            if (wiz * woz >= 0) continue;
+            ring += (1 - F) * d.G1(wox, woy, woz, mx, my, mz) * d.G1(wix, 0, wiz, mx, my, mz) * ci / (mu * mz);
+        }
+        total += wgt * ring / nPhi;
+    }
+    return total;
+}
+
+/* libcore/spline.cpp:23-60 */
+double cubicInterp(double x, const double *v, int size) {
+    if (!(x >= 0 && x <= 1)) return 0;
+    double t = x * (size - 1);
+    const int k = std::max(0, std::min((int)t, size - 2));
+    const double f0 = v[k], f1 = v[k + 1];
+    const double d0 = k > 0 ? 0.5 * (v[k + 1] - v[k - 1]) : v[k + 1] - v[k];
+    const double d1 = k + 2 < size ? 0.5 * (v[k + 2] - v[k]) : v[k + 1] - v[k];
+    t -= k;
+    const double t2 = t * t, t3 = t2 * t;
+    return (2 * t3 - 3 * t2 + 1) * f0 + (-2 * t3 + 3 * t2) * f1 + (t3 - 2 * t2 + t) * d0 + (t3 - t2) * d1;
+}
+} /* namespace */
+
+void roughTransmittanceTable(int distr, float alpha, float eta, float *trans100, float *diffTrans) {
+    struct Entry { float t[100]; float d; };
+    static std::map<std::tuple<int, float, float>, Entry> cache;
+    static std::mutex mtx;
+    std::lock_guard<std::mutex> g(mtx);
+    const auto key = std::make_tuple(distr, alpha, eta);
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        std::vector<double> gx, gw; gaussLegendre01(96, gx, gw);
+        MF d{ distr, (double)alpha };
+        double vals[100];
+        Entry e;
+        for (int i = 0; i < 100; ++i) {
+            double t = i / 99.0; if (i == 0) t = 0.1 / 99.0;          /* utils/rdielprec.cpp:88-95 */
+            vals[i] = transmittanceAt(d, (double)eta, t * t * t * t, gx, gw);
+            e.t[i] = (float)vals[i];
+        }
+        /* diffuse transmittance 2 int_0^1 mu T(mu) dmu through the interpolant (rdielprec.cpp:58-62) */
+        double acc = 0;
+        for (size_t i = 0; i < gx.size(); ++i) acc += gw[i] * 2 * gx[i] * cubicInterp(std::pow(gx[i], 0.25), vals, 100);
+        e.d = (float)acc;
+        it = cache.emplace(key, e).first;
+    }
+    std::memcpy(trans100, it->second.t, sizeof(float) * 100);
+    *diffTrans = it->second.d;
+}
+
+/* ---- scene flattening ---- */
+static void conserve(float *c) {   /* librender/bsdf.cpp:105-130 for a constant texture */
+    const float m = std::max(c[0], std::max(c[1], c[2]));
+    if (m > 1.0f) { const float s = 0.99f * (1.0f / m); c[0] *= s; c[1] *= s; c[2] *= s; }
+}
+static float lum(const float *c) { return c[0] * 0.212671f + c[1] * 0.715160f + c[2] * 0.072169f; }
+
+static void mat4mul(const double a[16], const double b[16], double r[16]) {
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+        double s = 0; for (int k = 0; k < 4; ++k) s += a[4 * i + k] * b[4 * k + j];
+        r[4 * i + j] = s;
+    }
+}
+static bool mat4inv(const double m[16], double out[16]) {
+    double a[4][8];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { a[i][j] = m[4 * i + j]; a[i][j + 4] = i == j; }
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 4; ++r) if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+        if (a[piv][c] == 0) return false;
+        for (int j = 0; j < 8; ++j) std::swap(a[c][j], a[piv][j]);
+        const double d = a[c][c];
+        for (int j = 0; j < 8; ++j) a[c][j] /= d;
+        for (int r = 0; r < 4; ++r) if (r != c) { const double f = a[r][c]; for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j]; }
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out[4 * i + j] = a[i][j + 4];
+    return true;
+}
+
+#define KKD_FAIL(code, msg) do { err = (msg); if (errCode) *errCode = (code); return false; } while (0)
+
+bool flattenScene(const kkd_scene_desc *sd, HostScene &hs, std::string &err, int *errCode) {
+    if (!sd) KKD_FAIL(KKD_ERR_INVALID, "scene description is NULL");
+    if (sd->abi_version != KKD_ABI_VERSION) KKD_FAIL(KKD_ERR_INVALID, "scene description has a different ABI version");
+    if (!sd->positions || !sd->indices || !sd->n_verts || !sd->n_tris) KKD_FAIL(KKD_ERR_INVALID, "scene has no geometry");
+    if (!sd->n_shapes || !sd->shapes || !sd->n_materials || !sd->materials) KKD_FAIL(KKD_ERR_INVALID, "scene has no shapes or materials");
+    if (sd->n_emitters && !sd->emitters) KKD_FAIL(KKD_ERR_INVALID, "emitters pointer is NULL");
+    if (sd->n_verts > 0xFFFFFFFFull) KKD_FAIL(KKD_ERR_INVALID, "more than 2^32 vertices");
+    hs.nVerts = sd->n_verts; hs.nTris = sd->n_tris;
+    hs.hasNormals = sd->normals != nullptr; hs.hasTexcoords = sd->texcoords != nullptr;
+    for (uint64_t i = 0; i < 3 * sd->n_tris; ++i)
+        if (sd->indices[i] >= sd->n_verts) KKD_FAIL(KKD_ERR_INVALID, "vertex index out of range");
+
+    /* shapes: must tile the triangle array in addShape order (skdtree.cpp:49-70) */
+    hs.shapes.resize(sd->n_shapes); hs.shapeOfPrim.assign(sd->n_tris, 0);
+    uint64_t expect = 0;
+    for (uint32_t s = 0; s < sd->n_shapes; ++s) {
+        const kkd_shape &k = sd->shapes[s];
+        if (k.first_prim != expect) KKD_FAIL(KKD_ERR_INVALID, "shapes must tile the triangle array in order");
+        expect += k.n_prims;
+        if (expect > sd->n_tris) KKD_FAIL(KKD_ERR_INVALID, "shape exceeds the triangle array");
+        if (k.material_id < 0 || (uint32_t)k.material_id >= sd->n_materials) KKD_FAIL(KKD_ERR_INVALID, "material id out of range");
+        if (k.emitter_id >= (int32_t)sd->n_emitters) KKD_FAIL(KKD_ERR_INVALID, "emitter id out of range");
+        if ((k.flags & KKD_SHAPE_HAS_NORMALS) && !sd->normals) KKD_FAIL(KKD_ERR_INVALID, "shape wants normals but none given");
+        if ((k.flags & KKD_SHAPE_HAS_TEXCOORDS) && !sd->texcoords) KKD_FAIL(KKD_ERR_INVALID, "shape wants texcoords but none given");
+        DShape &d = hs.shapes[s];
+        d.firstPrim = k.first_prim; d.nPrims = k.n_prims; d.material = k.material_id; d.emitter = k.emitter_id < 0 ? -1 : k.emitter_id;
+        d.flags = k.flags; d.pad[0] = d.pad[1] = d.pad[2] = 0;
+        for (uint32_t p = 0; p < k.n_prims; ++p) hs.shapeOfPrim[k.first_prim + p] = s;
+    }
+    if (expect != sd->n_tris) KKD_FAIL(KKD_ERR_INVALID, "shapes do not cover all triangles");
+
+    /* materials */
+    hs.materials.resize(sd->n_materials); hs.rtTables.clear();
+    for (uint32_t i = 0; i < sd->n_materials; ++i) {
+        const kkd_material &k = sd->materials[i]; DMaterial &m = hs.materials[i];
+        std::memset(&m, 0, sizeof(m));
+        m.type = k.type; m.distr = k.distribution; m.sampleVisible = k.sample_visible != 0; m.nonlinear = k.nonlinear != 0;
+        m.nested0 = k.nested[0]; m.nested1 = k.nested[1]; m.tableOffset = -1;
+        m.alphaU = std::max(k.alpha_u, 1e-4f); m.alphaV = std::max(k.alpha_v, 1e-4f);   /* microfacet.h:70-71 */
+        m.eta = k.eta;
+        for (int c = 0; c < 3; ++c) {
+            m.refl[c] = k.reflectance[c]; m.specRefl[c] = k.specular_reflectance[c]; m.specTrans[c] = k.specular_transmittance[c];
+            m.condEta[c] = k.cond_eta[c]; m.condK[c] = k.cond_k[c];
+        }
+        if (m.distr < 0 || m.distr > KKD_DISTR_PHONG) KKD_FAIL(KKD_ERR_INVALID, "unknown microfacet distribution");
+        if (m.distr == KKD_DISTR_PHONG) m.sampleVisible = 0;   /* microfacet.h:85-93 */
+        switch (m.type) {
+            case KKD_BSDF_DIFFUSE: {
+                conserve(m.refl);
+                const bool nz = std::max(m.refl[0], std::max(m.refl[1], m.refl[2])) > 0;
+                m.typeFlags = nz ? (EDiffuseReflection | EFrontSide) : 0u;
+                break;
+            }
+            case KKD_BSDF_ROUGHCONDUCTOR:
+                conserve(m.specRefl);
+                m.typeFlags = EGlossyReflection | EFrontSide;
+                break;
+            case KKD_BSDF_ROUGHPLASTIC: {
+                if (m.distr == KKD_DISTR_PHONG) KKD_FAIL(KKD_ERR_UNSUPPORTED, "roughplastic with the phong distribution is not supported");
+                if (!(m.eta > 0.f) || m.eta == 1.f) KKD_FAIL(KKD_ERR_INVALID, "roughplastic: bad relative index of refraction");
+                conserve(m.specRefl); conserve(m.refl);
+                m.alphaV = m.alphaU;
+                const float dAvg = lum(m.refl), sAvg = lum(m.specRefl);
+                m.specSamplingWeight = sAvg / (dAvg + sAvg);
+                m.invEta2 = 1.0f / (m.eta * m.eta);
+                m.tableOffset = (int32_t)hs.rtTables.size();
+                hs.rtTables.resize(hs.rtTables.size() + 100);
+                float dOut, dIn, inner[100];
+                roughTransmittanceTable(m.distr, m.alphaU, m.eta, hs.rtTables.data() + m.tableOffset, &dOut);
+                roughTransmittanceTable(m.distr, m.alphaU, 1.0f / m.eta, inner, &dIn);
+                m.fdr = 1.0f - std::min(1.0f, std::max(0.0f, dIn));
+                m.typeFlags = EGlossyReflection | EDiffuseReflection | EFrontSide;
+                break;
+            }
+            case KKD_BSDF_DIELECTRIC:
+                if (!(m.eta > 0.f)) KKD_FAIL(KKD_ERR_INVALID, "dielectric: bad relative index of refraction");
+                conserve(m.specRefl); conserve(m.specTrans);
+                m.typeFlags = EDeltaReflection | EDeltaTransmission | EFrontSide | EBackSide;
+                break;
+            case KKD_BSDF_TWOSIDED:
+                if (m.nested0 < 0 || (uint32_t)m.nested0 >= sd->n_materials || (m.nested1 >= 0 && (uint32_t)m.nested1 >= sd->n_materials))
+                    KKD_FAIL(KKD_ERR_INVALID, "twosided: bad nested material id");
+                if (m.nested1 < 0) m.nested1 = m.nested0;
+                break;
+            default: KKD_FAIL(KKD_ERR_INVALID, "unknown BSDF type");
+        }
+    }
+    for (DMaterial &m : hs.materials) if (m.type == KKD_BSDF_TWOSIDED) {   /* twosided.cpp:84-106 */
+        const DMaterial &a = hs.materials[m.nested0], &b = hs.materials[m.nested1];
+        if (a.type == KKD_BSDF_TWOSIDED || b.type == KKD_BSDF_TWOSIDED) KKD_FAIL(KKD_ERR_UNSUPPORTED, "twosided cannot nest twosided");
+        if ((a.typeFlags | b.typeFlags) & ETransmission) KKD_FAIL(KKD_ERR_INVALID, "twosided: only BRDFs can be nested");
+        m.typeFlags = 0;
+        if (a.typeFlags) m.typeFlags |= (a.typeFlags & ~EBackSide) | EFrontSide;
+        if (b.typeFlags) m.typeFlags |= (b.typeFlags & ~EFrontSide) | EBackSide;
+    }
+
+    /* emitters, scene emitter PDF, area CDFs */
+    hs.emitters.resize(sd->n_emitters); hs.emitterCdf.assign(1, 0.0f); hs.areaCdf.clear(); hs.envEmitter = -1;
+    std::vector<int64_t> shapeCdf(sd->n_shapes, -1); std::vector<float> shapeInvArea(sd->n_shapes, 0.f);
+    for (uint32_t i = 0; i < sd->n_emitters; ++i) {
+        const kkd_emitter &k = sd->emitters[i]; DEmitter &e = hs.emitters[i];
+        std::memset(&e, 0, sizeof(e));
+        e.type = k.type; e.shape = k.shape_id; e.weight = k.sampling_weight;
+        for (int c = 0; c < 3; ++c) { e.radiance[c] = k.radiance[c]; e.position[c] = k.position[c]; }
+        if (!(e.weight >= 0.f)) KKD_FAIL(KKD_ERR_INVALID, "emitter sampling weight must be >= 0");
+        if (e.type == KKD_EMITTER_AREA) {
+            if (e.shape < 0 || (uint32_t)e.shape >= sd->n_shapes) KKD_FAIL(KKD_ERR_INVALID, "area emitter: bad shape id");
+            const DShape &s = hs.shapes[e.shape];
+            if (s.emitter != (int32_t)i) KKD_FAIL(KKD_ERR_INVALID, "area emitter and its shape do not reference each other");
+            if (shapeCdf[e.shape] < 0) {
+                shapeCdf[e.shape] = (int64_t)hs.areaCdf.size();
+                const size_t base = hs.areaCdf.size();
+                hs.areaCdf.push_back(0.0f);
+                for (uint32_t p = s.firstPrim; p < s.firstPrim + s.nPrims; ++p) {
+                    const float *a = sd->positions + 3 * (size_t)sd->indices[3 * (size_t)p], *b = sd->positions + 3 * (size_t)sd->indices[3 * (size_t)p + 1],
+                                *c = sd->positions + 3 * (size_t)sd->indices[3 * (size_t)p + 2];
+                    const f3 s1(b[0] - a[0], b[1] - a[1], b[2] - a[2]), s2(c[0] - a[0], c[1] - a[1], c[2] - a[2]);
+                    hs.areaCdf.push_back(hs.areaCdf.back() + 0.5f * length(cross(s1, s2)));
+                }
+                const float sum = hs.areaCdf.back();
+                if (!(sum > 0.f)) KKD_FAIL(KKD_ERR_INVALID, "area emitter on a shape with zero surface area");
+                const float norm = 1.0f / sum;
+                for (size_t j = base + 1; j < hs.areaCdf.size(); ++j) hs.areaCdf[j] *= norm;
+                hs.areaCdf.back() = 1.0f;
+                shapeInvArea[e.shape] = 1.0f / sum;
+            }
+            e.cdfOffset = (uint32_t)shapeCdf[e.shape]; e.invArea = shapeInvArea[e.shape];
+            e.firstPrim = s.firstPrim; e.nPrims = s.nPrims; e.shapeFlags = s.flags;
+        } else if (e.type == KKD_EMITTER_POINT) {
+            e.shape = -1;
+        } else if (e.type == KKD_EMITTER_ENVMAP) {
+            if (hs.envEmitter >= 0) KKD_FAIL(KKD_ERR_INVALID, "more than one environment emitter");
+            hs.envEmitter = (int)i; e.shape = -1;
+        } else KKD_FAIL(KKD_ERR_INVALID, "unknown emitter type");
+        hs.emitterCdf.push_back(hs.emitterCdf.back() + e.weight);
+    }
+    for (uint32_t s = 0; s < sd->n_shapes; ++s)
+        if (hs.shapes[s].emitter >= 0 && hs.emitters[hs.shapes[s].emitter].type != KKD_EMITTER_AREA)
+            KKD_FAIL(KKD_ERR_INVALID, "shape references a non-area emitter");
+    hs.emitterNormalization = 0.f;
+    if (sd->n_emitters) {
+        const float sum = hs.emitterCdf.back();
+        if (!(sum > 0.f)) KKD_FAIL(KKD_ERR_INVALID, "all emitter sampling weights are zero");
+        hs.emitterNormalization = 1.0f / sum;
+        for (size_t j = 1; j < hs.emitterCdf.size(); ++j) hs.emitterCdf[j] *= hs.emitterNormalization;
+        hs.emitterCdf.back() = 1.0f;
+    }
+
+    /* environment map (envmap.cpp:260-329) */
+    std::memset(&hs.env, 0, sizeof(hs.env));
+    if (hs.envEmitter >= 0) {
+        const kkd_envmap &k = sd->envmap;
+        if (!k.width || !k.height || !k.texels) KKD_FAIL(KKD_ERR_INVALID, "envmap emitter without texels");
+        if (k.width > 65535 || k.height > 65535) KKD_FAIL(KKD_ERR_INVALID, "envmap larger than 65535 pixels per side");   /* envmap.cpp:161-163 */
+        const int w = (int)k.width, h = (int)k.height;
+        hs.env.w = w; hs.env.h = h; hs.env.scale = k.scale;
+        hs.envTexels.resize((size_t)w * h * 4);
+        hs.envCdfCols.assign((size_t)(w + 1) * h, 0.f); hs.envCdfRows.assign(h + 1, 0.f); hs.envRowWeights.assign(h, 0.f);
+        size_t colPos = 0, rowPos = 0; float rowSum = 0.0f;
+        hs.envCdfRows[rowPos++] = 0;
+        for (int y = 0; y < h; ++y) {
+            float colSum = 0;
+            hs.envCdfCols[colPos++] = 0;
+            for (int x = 0; x < w; ++x) {
+                float rgb[3];
+                for (int c = 0; c < 3; ++c) {
+                    const float v = k.texels[((size_t)y * w + x) * 3 + c];
+                    if (!(v >= 0.f) || !std::isfinite(v)) KKD_FAIL(KKD_ERR_INVALID, "envmap texel is negative or not finite");
+                    const uint16_t hb = floatToHalf(v);
+                    hs.envTexels[((size_t)y * w + x) * 4 + c] = hb;
+                    rgb[c] = halfToFloat(hb);
+                }
+                hs.envTexels[((size_t)y * w + x) * 4 + 3] = 0;
+                colSum += lum(rgb);
+                hs.envCdfCols[colPos++] = colSum;
+            }
+            const float normalization = 1.0f / colSum;
+            for (int x = 1; x < w; ++x) hs.envCdfCols[colPos - x - 1] *= normalization;
+            hs.envCdfCols[colPos - 1] = 1.0f;
+            const float weight = std::sin((y + 0.5f) * kPi / h);
+            hs.envRowWeights[y] = weight;
+            rowSum += colSum * weight;
+            hs.envCdfRows[rowPos++] = rowSum;
+        }
+        if (!(rowSum > 0.f)) KKD_FAIL(KKD_ERR_INVALID, "envmap is black");
+        const float norm = 1.0f / rowSum;
+        for (int y = 1; y < h; ++y) hs.envCdfRows[rowPos - y - 1] *= norm;
+        hs.envCdfRows[rowPos - 1] = 1.0f;
+        hs.env.normalization = 1.0f / (rowSum * (2 * kPi / w) * (kPi / h));
+        hs.env.pixelSizeX = 2 * kPi / w; hs.env.pixelSizeY = kPi / h;
+        for (int i = 0; i < 9; ++i) hs.env.toWorld[i] = k.to_world[i];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) hs.env.toLocal[3 * i + j] = k.to_world[3 * j + i];
+        for (int i = 0; i < 3; ++i) hs.env.center[i] = k.bsphere_center[i];
+        hs.env.radius = k.bsphere_radius;
+        if (!(hs.env.radius > 0.f)) KKD_FAIL(KKD_ERR_INVALID, "envmap: bounding sphere radius must be positive");
+    }
+
+    /* sensor (perspective.cpp:126-163) */
+    {
+        const kkd_sensor &s = sd->sensor;
+        if (!s.film_width || !s.film_height || !s.crop_width || !s.crop_height) KKD_FAIL(KKD_ERR_INVALID, "film has zero size");
+        if (s.crop_offset_x + s.crop_width > s.film_width || s.crop_offset_y + s.crop_height > s.film_height) KKD_FAIL(KKD_ERR_INVALID, "crop window exceeds the film");
+        if (!(s.xfov_deg > 0.f && s.xfov_deg < 180.f)) KKD_FAIL(KKD_ERR_INVALID, "field of view must be in (0, 180)");
+        if (!(s.near_clip > 0.f && s.far_clip > s.near_clip)) KKD_FAIL(KKD_ERR_INVALID, "bad clipping planes");
+        const double aspect = (double)s.film_width / (double)s.film_height;
+        const double rsx = (double)s.crop_width / s.film_width, rsy = (double)s.crop_height / s.film_height;
+        const double rox = (double)s.crop_offset_x / s.film_width, roy = (double)s.crop_offset_y / s.film_height;
+        const double n = s.near_clip, f = s.far_clip, recip = 1.0 / (f - n), cot = 1.0 / std::tan((double)s.xfov_deg * 0.5 * M_PI / 180.0);
+        const double P[16] = { cot, 0, 0, 0, 0, cot, 0, 0, 0, 0, f * recip, -n * f * recip, 0, 0, 1, 0 };   /* transform.cpp:99-123 */
+        const double T1[16] = { 1, 0, 0, -1, 0, 1, 0, -1 / aspect, 0, 0, 1, 0, 0, 0, 0, 1 };
+        const double S1[16] = { -0.5, 0, 0, 0, 0, -0.5 * aspect, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
+        const double T2[16] = { 1, 0, 0, -rox, 0, 1, 0, -roy, 0, 0, 1, 0, 0, 0, 0, 1 };
+        const double S2[16] = { 1 / rsx, 0, 0, 0, 0, 1 / rsy, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
+        double a[16], b[16], c2s[16], s2c[16];
+        mat4mul(T1, P, a); mat4mul(S1, a, b); mat4mul(T2, b, a); mat4mul(S2, a, c2s);
+        if (!mat4inv(c2s, s2c)) KKD_FAIL(KKD_ERR_INVALID, "singular camera projection");
+        for (int i = 0; i < 16; ++i) hs.sensor.s2c[i] = (float)s2c[i];
+        for (int i = 0; i < 12; ++i) hs.sensor.toWorld[i] = s.to_world[i];
+        hs.sensor.nearClip = s.near_clip; hs.sensor.farClip = s.far_clip;
+        hs.sensor.invResX = 1.0f / (float)s.crop_width; hs.sensor.invResY = 1.0f / (float)s.crop_height;
+        hs.sensor.cropW = (int)s.crop_width; hs.sensor.cropH = (int)s.crop_height; hs.sensor.filmHasAlpha = s.film_has_alpha != 0; hs.sensor.pad = 0;
+        if (s.rfilter_type < 0 || s.rfilter_type > KKD_RFILTER_LANCZOS) KKD_FAIL(KKD_ERR_INVALID, "unknown reconstruction filter");
+        if (!(s.rfilter_radius > 0.f)) KKD_FAIL(KKD_ERR_INVALID, "filter radius must be positive");
+        configureFilter(s.rfilter_type, s.rfilter_radius, s.rfilter_param, hs.filter);
+        if (hs.filter.border > 6) KKD_FAIL(KKD_ERR_UNSUPPORTED, "reconstruction filter radius above 6.5 pixels");
+    }
+
+    /* acceleration structure */
+    if (!hs.bvh.build(sd->positions, sd->indices, sd->n_tris, hs.shapeOfPrim.data(), err)) { if (errCode) *errCode = KKD_ERR_INVALID; return false; }
+    return true;
+}
+
+} /* namespace kkd */

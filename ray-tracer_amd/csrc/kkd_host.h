@@ -1,0 +1,46 @@
+/*
+ * kkd_host.h -- host-side flattening of a kkd_scene_desc into the arrays the GPU keeps resident.
+ * Replaces Scene::initialize / ShapeKDTree::build / EnvironmentMap::configure / BSDF::configure /
+ * ReconstructionFilter::configure of the reference (see kkd_host.cpp for file:line).
+ */
+#pragma once
+#include "kkd_types.h"
+#include "kkd_bvh.h"
+#include "../../include/kkdirect.h"
+#include <string>
+#include <vector>
+
+namespace kkd {
+
+struct HostScene {
+    BVH4 bvh;
+    std::vector<uint32_t> shapeOfPrim;
+    std::vector<DShape> shapes;
+    std::vector<DMaterial> materials;
+    std::vector<DEmitter> emitters;
+    std::vector<float> emitterCdf, areaCdf, rtTables;
+    int envEmitter = -1;
+    float emitterNormalization = 0.f;
+    /* envmap */
+    DEnvMap env{};                   /* pointer members filled after upload */
+    std::vector<uint16_t> envTexels; /* RGBA half */
+    std::vector<float> envCdfRows, envCdfCols, envRowWeights;
+    DSensor sensor{};
+    DFilter filter{};
+    uint64_t nVerts = 0, nTris = 0;
+    bool hasNormals = false, hasTexcoords = false;
+};
+
+/* Validates the description and fills everything except device pointers.  false + err on failure. */
+bool flattenScene(const kkd_scene_desc *sd, HostScene &hs, std::string &err, int *errCode);
+
+/* rough-dielectric transmittance T(cosTheta) for one (distribution, alpha, eta): 100 knots at
+ * cosTheta^(1/4) = i/99 plus the diffuse transmittance (what bsdfs/rtrans.h yields after setEta/setAlpha). */
+void roughTransmittanceTable(int distr, float alpha, float eta, float *trans100, float *diffTrans);
+
+void configureFilter(int type, float radius, const float *param, DFilter &f);
+
+uint16_t floatToHalf(float f);
+float halfToFloat(uint16_t h);
+
+} /* namespace kkd */

@@ -1,0 +1,40 @@
+/* kkd_kernels.h -- launch interface between the C-ABI host code (kkd_api.hip) and the gfx950 kernels. */
+#pragma once
+#include <hip/hip_runtime.h>
+#include "kkd_types.h"
+
+namespace kkd {
+
+struct DeviceCounters { unsigned long long samples, raysClosest, raysShadow, nodes, tris, pad[3]; };
+
+/* One batch = work items [w0, w0 + count) of the render; see mapWorkItem() in kkd_kernels.hip. */
+struct BatchParams {
+    uint64_t w0; uint64_t seed;
+    uint32_t count, stride;          /* stride: element pitch between the per-sample planes of multi-sample buffers */
+    uint32_t g, gShift, chunks, spp, sampleFirst;
+    uint32_t nB, nL, hideEmitters;
+    uint32_t bs, bsPow2, nbx, nby, tileIndex, tileCount, nTilesMine;
+    int32_t W, H;
+};
+
+/* SoA work buffers of one batch (all device memory). */
+struct WaveBuffers {
+    DHit *hits;          /* primary hits                       [stride]      */
+    float4 *accum;       /* Le / environment + alpha           [stride]      */
+    float4 *refN;        /* DirectSamplingRecord::refN         [stride]      */
+    DRay *bsdfRays;      /*                                    [nB * stride] */
+    DHit *bsdfHits;      /*                                    [nB * stride] */
+    float4 *brec0;       /* bsdf weight rgb, +-pdf (<0: delta) [nB * stride] */
+    DRay *shadowRays;    /*                                    [nL * stride] */
+    uint32_t *occluded;  /*                                    [nL * stride] */
+    float4 *lrec;        /* MIS-weighted light contribution    [nL * stride] */
+};
+
+/* stackClass: 0 = 32-entry LDS stack, 256-thread blocks; 1 = 96-entry stack, 64-thread blocks */
+void launchPrimary(hipStream_t st, int stackClass, const DScene &sc, const BatchParams &bp, DHit *hits, DeviceCounters *ctr);
+/* outMode: 0 = DHit with LeafTri slot, 1 = DHit with global primitive id, 2 = uint32 occlusion flags (anyHit only) */
+void launchTrace(hipStream_t st, int stackClass, const DScene &sc, const DRay *rays, uint64_t n, bool anyHit, bool count, int outMode, void *out, DeviceCounters *ctr);
+void launchShade(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb);
+void launchResolve(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb, float *film, DeviceCounters *ctr);
+
+} /* namespace kkd */

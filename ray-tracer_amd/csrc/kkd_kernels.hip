@@ -1,0 +1,322 @@
+/*
+ * kkd_kernels.hip -- the gfx950 kernels of libkkdirect, wavefront style: every stage is one launch over
+ * a batch of camera samples and hands the next stage small SoA records that stay resident in HBM / the
+ * 256 MiB Infinity Cache.
+ *
+ *   kPrimary   sensor ray generation fused with closest-hit traversal      (perspective.cpp:271-298 +
+ *                                                                           skdtree.cpp:112-142)
+ *   kShade     hit record, Le, BSDF sampling, emitter sampling, MIS terms   (kk/direct.cpp:50-160)
+ *   kTrace     closest-hit / any-hit traversal of a ray buffer              (skdtree.cpp:112-142, 207-226)
+ *   kResolve   BSDF-ray emitter lookup + light pdf, MIS sum, filtered splat (kk/direct.cpp:105-123,162-178,
+ *                                                                           integrator.cpp:183-184, ImageBlock::put)
+ * Reference paths are relative to /root/reference/src.
+ *
+ * Work item -> camera sample mapping (replaces the Hilbert-curve pixel walk of renderproc.cpp:79 and the
+ * spp loop of integrator.cpp:162-186): the `g` lanes of a lane group (g = min(64, pow2ceil(spp))) hold
+ * g samples of ONE pixel, so primary rays of a wave are maximally coherent and the film splat can be
+ * reduced across the group before any atomic is issued.
+ */
+#include "kkd_kernels.h"
+#include "kkd_trace.h"
+#include "kkd_bsdf.h"
+#include "kkd_shade.h"
+
+namespace kkd {
+
+/* ---- work mapping ------------------------------------------------------------------------------ */
+struct SampleId { int X, Y; uint32_t pixel, sample; bool active; };
+
+__device__ __forceinline__ uint32_t compact1by1(uint32_t x) {
+    x &= 0x55555555u; x = (x ^ (x >> 1)) & 0x33333333u; x = (x ^ (x >> 2)) & 0x0f0f0f0fu;
+    x = (x ^ (x >> 4)) & 0x00ff00ffu; x = (x ^ (x >> 8)) & 0x0000ffffu; return x;
+}
+
+__device__ __forceinline__ SampleId mapWorkItem(const BatchParams &bp, uint32_t i) {
+    SampleId s;
+    const uint64_t w = bp.w0 + i;
+    const uint64_t group = w >> bp.gShift;
+    const uint32_t j = (uint32_t)w & (bp.g - 1u);
+    const uint32_t chunk = (uint32_t)(group % bp.chunks);
+    const uint64_t slot = group / bp.chunks;
+    const uint32_t pixPerTile = bp.bs * bp.bs;
+    const uint32_t tileLocal = (uint32_t)(slot / pixPerTile), pin = (uint32_t)(slot % pixPerTile);
+    const uint32_t tile = bp.tileIndex + tileLocal * bp.tileCount;
+    const uint32_t tx = tile % bp.nbx, ty = tile / bp.nbx;
+    uint32_t px, py;
+    if (bp.bsPow2) { px = compact1by1(pin); py = compact1by1(pin >> 1); }
+    else { px = pin % bp.bs; py = pin / bp.bs; }
+    s.X = (int)(tx * bp.bs + px); s.Y = (int)(ty * bp.bs + py);
+    s.sample = chunk * bp.g + j;
+    s.active = i < bp.count && tileLocal < bp.nTilesMine && s.X < bp.W && s.Y < bp.H && s.sample < bp.spp;
+    s.pixel = (uint32_t)(s.Y * bp.W + s.X);
+    s.sample += bp.sampleFirst;
+    return s;
+}
+
+__device__ __forceinline__ DRay primaryRay(const DScene &sc, const BatchParams &bp, const SampleId &s, float &sx, float &sy) {
+    const f2 jit = sample2D(bp.seed, s.pixel, s.sample, 0);
+    sx = (float)s.X + jit.x; sy = (float)s.Y + jit.y;      /* integrator.cpp:171 */
+    return sensorRay(sc.sensor, sx, sy);
+}
+
+__device__ __forceinline__ void countRays(bool traced, unsigned long long *counter) {
+    const unsigned long long m = __ballot(traced);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(counter, (unsigned long long)__popcll(m));
+}
+
+/* ---- K1+K2: primary rays ------------------------------------------------------------------------- */
+template <int STACK, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) kPrimary(DScene sc, BatchParams bp, DHit *__restrict__ hits, DeviceCounters *ctr) {
+    __shared__ uint32_t sstack[STACK * BLOCK];
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const SampleId s = mapWorkItem(bp, i);
+    DRay ray; ray.maxt = -1.f; ray.mint = 0.f; ray.ox = ray.oy = ray.oz = 0.f; ray.dx = ray.dy = 0.f; ray.dz = 1.f;
+    float sx, sy;
+    if (s.active) ray = primaryRay(sc, bp, s, sx, sy);
+    uint32_t nn = 0, nt = 0;
+    const DHit h = traverse<false, false, STACK, BLOCK>(sc.nodes, sc.tris, ray, sstack, nn, nt);
+    if (i < bp.count) hits[i] = h;
+    countRays(s.active, &ctr->raysClosest);
+}
+
+/* ---- generic ray-buffer traversal ------------------------------------------------------------------ */
+/* OUT: 0 = DHit with LeafTri slot (internal), 1 = DHit with global primitive id (C ABI), 2 = occlusion word */
+template <bool ANY, bool COUNT, int OUT, int STACK, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) kTrace(const Node4 *__restrict__ nodes, const LeafTri *__restrict__ tris,
+                                                const DRay *__restrict__ rays, uint64_t n, void *__restrict__ out, DeviceCounters *ctr) {
+    __shared__ uint32_t sstack[STACK * BLOCK];
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    DRay ray; ray.maxt = -1.f; ray.mint = 0.f; ray.ox = ray.oy = ray.oz = 0.f; ray.dx = ray.dy = 0.f; ray.dz = 1.f;
+    if (i < n) ray = rays[i];
+    uint32_t nn = 0, nt = 0;
+    DHit h = traverse<ANY, COUNT, STACK, BLOCK>(nodes, tris, ray, sstack, nn, nt);
+    if (i < n) {
+        if (OUT == 2) reinterpret_cast<uint32_t *>(out)[i] = h.id != kNoHit ? 1u : 0u;
+        else {
+            if (OUT == 1 && h.id != kNoHit) h.id = tris[h.id].prim;
+            reinterpret_cast<DHit *>(out)[i] = h;
+        }
+    }
+    if (ctr) {
+        const bool traced = i < n && ray.maxt > adaptiveMinT<ANY>(ray.mint, ray.ox, ray.oy, ray.oz);
+        countRays(traced, ANY ? &ctr->raysShadow : &ctr->raysClosest);
+        if (COUNT) {
+            for (int m = 32; m > 0; m >>= 1) { nn += __shfl_xor(nn, m); nt += __shfl_xor(nt, m); }
+            if ((threadIdx.x & 63) == 0) { atomicAdd(&ctr->nodes, (unsigned long long)nn); atomicAdd(&ctr->tris, (unsigned long long)nt); }
+        }
+    }
+}
+
+/* ---- K4: shade ------------------------------------------------------------------------------------ */
+__device__ __forceinline__ void killRay(DRay &r) { r.ox = r.oy = r.oz = 0.f; r.dx = r.dy = 0.f; r.dz = 1.f; r.mint = 0.f; r.maxt = -1.f; }
+__device__ __forceinline__ void storeRay(DRay *dst, const DRay &r) {
+    float4 *p = reinterpret_cast<float4 *>(dst);
+    p[0] = make_float4(r.ox, r.oy, r.oz, r.mint); p[1] = make_float4(r.dx, r.dy, r.dz, r.maxt);
+}
+
+__global__ void __launch_bounds__(256) kShade(DScene sc, BatchParams bp, WaveBuffers wb) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= bp.count) return;
+    const SampleId s = mapWorkItem(bp, i);
+    const uint32_t nB = bp.nB, nL = bp.nL;
+    float4 accum = make_float4(0.f, 0.f, 0.f, 1.f);
+    const DHit hit = wb.hits[i];
+    bool shade = false;
+    Its its; DRay ray; float sx, sy;
+    if (s.active) {
+        ray = primaryRay(sc, bp, s, sx, sy);
+        if (hit.id == kNoHit) {                                    /* kk/direct.cpp:55-60 */
+            if (sc.sensor.filmHasAlpha) accum.w = 0.f;
+            if (!bp.hideEmitters && sc.envEmitter >= 0) { const f3 e = envEval(sc.env, f3(ray.dx, ray.dy, ray.dz)); accum.x = e.x; accum.y = e.y; accum.z = e.z; }
+        } else shade = true;
+    }
+    if (!shade) {
+        DRay dead; killRay(dead);
+        for (uint32_t b = 0; b < nB; ++b) { storeRay(wb.bsdfRays + (size_t)b * bp.stride + i, dead); wb.brec0[(size_t)b * bp.stride + i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        for (uint32_t l = 0; l < nL; ++l) { storeRay(wb.shadowRays + (size_t)l * bp.stride + i, dead); wb.lrec[(size_t)l * bp.stride + i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        wb.accum[i] = accum;
+        return;
+    }
+    const f3 rd(ray.dx, ray.dy, ray.dz);
+    fillIntersection<true>(sc, rd, hit, its);
+    if (its.emitter >= 0 && !bp.hideEmitters) {                      /* :66-67 */
+        const f3 le = areaEval(sc.emitters[its.emitter], its.sh.n, -rd);
+        accum.x += le.x; accum.y += le.y; accum.z += le.z;
+    }
+    const uint32_t btype = sc.materials[its.material].typeFlags;
+    const f3 refN = (btype & (ETransmission | EBackSide)) ? f3(0.f) : its.sh.n;   /* DirectSamplingRecord(its) */
+    const float cB = nB / (float)(nB + nL), cL = nL / (float)(nB + nL);            /* :163-166 */
+
+    /* integrateBrdf :74-104 -- the part before the ray is traced */
+    for (uint32_t b = 0; b < nB; ++b) {
+        const f2 u = sample2D(bp.seed, s.pixel, s.sample, 2u + 2u * b);
+        f3 woLocal; float bsdfPdf; uint32_t sampledType;
+        const f3 bsdfVal = sampleBsdf(sc, its.material, its.wi, u, woLocal, bsdfPdf, sampledType);
+        DRay r; killRay(r);
+        float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!isZero(bsdfVal)) {
+            const f3 wo = its.sh.toWorld(woLocal);
+            if (dot(its.geoN, wo) * woLocal.z > 0.f) {               /* :96-99 */
+                r.ox = its.p.x; r.oy = its.p.y; r.oz = its.p.z; r.mint = kEpsilon;
+                r.dx = wo.x; r.dy = wo.y; r.dz = wo.z; r.maxt = kInf;
+                rec = make_float4(bsdfVal.x, bsdfVal.y, bsdfVal.z, (sampledType & EDelta) ? -bsdfPdf : bsdfPdf);
+            }
+        }
+        storeRay(wb.bsdfRays + (size_t)b * bp.stride + i, r);
+        wb.brec0[(size_t)b * bp.stride + i] = rec;
+    }
+    wb.refN[i] = make_float4(refN.x, refN.y, refN.z, 0.f);
+
+    /* integrateLight :127-160 -- everything but the visibility test, already MIS-weighted (:172-177) */
+    for (uint32_t l = 0; l < nL; ++l) {
+        DRay r; killRay(r);
+        float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (btype && sc.nEmitters) {                                 /* :140 */
+            const f2 u = sample2D(bp.seed, s.pixel, s.sample, 2u + 2u * nB + 2u * l);
+            DirectRec dRec; dRec.ref = its.p; dRec.refN = refN; dRec.emitter = -1;
+            const f3 value = sampleEmitterDirectUnoccluded(sc, dRec, u);
+            if (!isZero(value)) {
+                const f3 woLocal = its.sh.toLocal(dRec.d);
+                const f3 bsdfVal = evalBsdf(sc, its.material, its.wi, woLocal);
+                if (!isZero(bsdfVal) && dot(its.geoN, dRec.d) * woLocal.z > 0.f) {   /* :154 */
+                    const bool onSurface = sc.emitters[dRec.emitter].type != KKD_EMITTER_POINT;
+                    const float bsdfPdf = onSurface ? pdfBsdf(sc, its.material, its.wi, woLocal) : 0.f;
+                    const float weight = cL * dRec.pdf / (cB * bsdfPdf + cL * dRec.pdf);
+                    const f3 contrib = value * bsdfVal * (weight / (float)nL);
+                    rec = make_float4(contrib.x, contrib.y, contrib.z, 0.f);
+                    r.ox = its.p.x; r.oy = its.p.y; r.oz = its.p.z; r.mint = kEpsilon;   /* scene.cpp:840-841 */
+                    r.dx = dRec.d.x; r.dy = dRec.d.y; r.dz = dRec.d.z; r.maxt = dRec.dist * (1.f - kShadowEpsilon);
+                }
+            }
+        }
+        storeRay(wb.shadowRays + (size_t)l * bp.stride + i, r);
+        wb.lrec[(size_t)l * bp.stride + i] = rec;
+    }
+    wb.accum[i] = accum;
+}
+
+/* ---- K5: resolve + splat ---------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveBuffers wb, float *__restrict__ film, DeviceCounters *ctr) {
+    __shared__ float sfilter[32];
+    if (threadIdx.x < 32) sfilter[threadIdx.x] = sc.filter.values[threadIdx.x];
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const SampleId s = mapWorkItem(bp, i);
+    const uint32_t nB = bp.nB, nL = bp.nL;
+    float val[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
+    float sx = 0.f, sy = 0.f;
+    if (s.active) {
+        const f2 jit = sample2D(bp.seed, s.pixel, s.sample, 0);
+        sx = (float)s.X + jit.x; sy = (float)s.Y + jit.y;
+        const float4 acc = wb.accum[i];
+        f3 L(acc.x, acc.y, acc.z);
+        const float4 rn = wb.refN[i];
+        const float cB = nB / (float)(nB + nL), cL = nL / (float)(nB + nL);
+        for (uint32_t b = 0; b < nB; ++b) {                        /* kk/direct.cpp:105-123 + :167-171 */
+            const float4 rec = wb.brec0[(size_t)b * bp.stride + i];
+            if (rec.w == 0.f) continue;
+            const DRay r = wb.bsdfRays[(size_t)b * bp.stride + i];
+            const DHit h = wb.bsdfHits[(size_t)b * bp.stride + i];
+            const f3 rd(r.dx, r.dy, r.dz);
+            DirectRec dRec; dRec.ref = f3(r.ox, r.oy, r.oz); dRec.refN = f3(rn.x, rn.y, rn.z);
+            f3 value;
+            if (h.id != kNoHit) {
+                Its bIts; fillIntersection<false>(sc, rd, h, bIts);
+                if (bIts.emitter < 0) continue;
+                value = areaEval(sc.emitters[bIts.emitter], bIts.sh.n, -rd);
+                dRec.p = bIts.p; dRec.n = bIts.sh.n; dRec.d = rd; dRec.dist = h.t; dRec.measure = 0; dRec.emitter = bIts.emitter;
+            } else {
+                if (sc.envEmitter < 0) continue;
+                value = envEval(sc.env, rd);
+                const f3 center(sc.env.center[0], sc.env.center[1], sc.env.center[2]);   /* envmap.cpp:358-374 */
+                float nearT, farT;
+                if (!sphereRayIntersect(center, sc.env.radius, dRec.ref, rd, nearT, farT) || nearT > 0.f || farT < 0.f) continue;
+                dRec.p = dRec.ref + rd * farT; dRec.n = normalize(center - dRec.p); dRec.measure = 0; dRec.emitter = sc.envEmitter;
+                dRec.d = rd; dRec.dist = farT;
+            }
+            const float bsdfPdf = fabsf(rec.w);
+            const float lightPdf = rec.w > 0.f ? pdfEmitterDirect(sc, dRec) : 0.f;
+            const float weight = cB * bsdfPdf / (cB * bsdfPdf + cL * lightPdf);
+            L += value * f3(rec.x, rec.y, rec.z) * (weight / (float)nB);
+        }
+        for (uint32_t l = 0; l < nL; ++l) {
+            const float4 rec = wb.lrec[(size_t)l * bp.stride + i];
+            if (wb.occluded[(size_t)l * bp.stride + i] == 0u) { L.x += rec.x; L.y += rec.y; L.z += rec.z; }
+        }
+        /* ImageBlock::put rejects samples with negative or non-finite components */
+        const bool ok = isfinite(L.x) && isfinite(L.y) && isfinite(L.z) && L.x >= 0.f && L.y >= 0.f && L.z >= 0.f;
+        if (ok) { val[0] = L.x; val[1] = L.y; val[2] = L.z; val[3] = acc.w; val[4] = 1.f; }
+    }
+    /* ---- filtered splat, reduced across the g lanes that share this pixel ---- */
+    const int b = sc.filter.border, win = 2 * b + 1, nVals = win * win * 5;
+    const float radius = sc.filter.radius, scale = sc.filter.scaleFactor;
+    const float posx = sx - 0.5f, posy = sy - 0.5f;
+    const int lox = (int)ceilf(posx - radius), hix = (int)floorf(posx + radius);
+    const int loy = (int)ceilf(posy - radius), hiy = (int)floorf(posy + radius);
+    const uint32_t g = bp.g, j = threadIdx.x & (g - 1u);
+    /* every lane of a group maps to the same pixel, also the inactive ones */
+    const int X = s.X, Y = s.Y, W = bp.W, H = bp.H;
+    float keep = 0.f; int k = 0;
+    for (int wy = 0; wy < win; ++wy) {
+        const int yi = Y - b + wy;
+        const float fy = (yi >= loy && yi <= hiy) ? sfilter[min((int)fabsf(((float)yi - posy) * scale), 31)] : 0.f;
+        for (int wx = 0; wx < win; ++wx) {
+            const int xi = X - b + wx;
+            const float fx = (xi >= lox && xi <= hix) ? sfilter[min((int)fabsf(((float)xi - posx) * scale), 31)] : 0.f;
+            const float w = fx * fy;
+#pragma unroll
+            for (int c = 0; c < 5; ++c, ++k) {
+                float v = w * val[c];
+                for (uint32_t m = 1; m < g; m <<= 1) v += __shfl_xor(v, (int)m);
+                const uint32_t kk = (uint32_t)k & (g - 1u);
+                if (kk == j) keep = v;
+                if (kk == g - 1u || k == nVals - 1) {
+                    const int kmine = (k - (int)kk) + (int)j;
+                    if (kmine < nVals && keep != 0.f) {
+                        const int c2 = kmine % 5, pix = kmine / 5, wx2 = pix % win, wy2 = pix / win;
+                        const int xo = X - b + wx2, yo = Y - b + wy2;
+                        if (xo >= 0 && xo < W && yo >= 0 && yo < H)
+                            atomicAdd(film + ((size_t)yo * W + xo) * 5 + c2, keep);
+                    }
+                    keep = 0.f;
+                }
+            }
+        }
+    }
+    if (ctr) countRays(s.active, &ctr->samples);
+}
+
+/* ---- host launchers ---------------------------------------------------------------------------------- */
+static inline uint32_t blocksFor(uint64_t n, uint32_t block) { return (uint32_t)((n + block - 1) / block); }
+
+void launchPrimary(hipStream_t st, int stackClass, const DScene &sc, const BatchParams &bp, DHit *hits, DeviceCounters *ctr) {
+    if (stackClass == 0) hipLaunchKernelGGL((kPrimary<32, 256>), dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, hits, ctr);
+    else hipLaunchKernelGGL((kPrimary<96, 64>), dim3(blocksFor(bp.count, 64)), dim3(64), 0, st, sc, bp, hits, ctr);
+}
+
+template <bool ANY, bool COUNT, int OUT>
+static void launchTraceT(hipStream_t st, int stackClass, const DScene &sc, const DRay *rays, uint64_t n, void *out, DeviceCounters *ctr) {
+    if (stackClass == 0) hipLaunchKernelGGL((kTrace<ANY, COUNT, OUT, 32, 256>), dim3(blocksFor(n, 256)), dim3(256), 0, st, sc.nodes, sc.tris, rays, n, out, ctr);
+    else hipLaunchKernelGGL((kTrace<ANY, COUNT, OUT, 96, 64>), dim3(blocksFor(n, 64)), dim3(64), 0, st, sc.nodes, sc.tris, rays, n, out, ctr);
+}
+
+void launchTrace(hipStream_t st, int stackClass, const DScene &sc, const DRay *rays, uint64_t n, bool anyHit, bool count, int outMode, void *out, DeviceCounters *ctr) {
+    if (n == 0) return;
+    if (anyHit) {
+        if (outMode == 2) { if (count) launchTraceT<true, true, 2>(st, stackClass, sc, rays, n, out, ctr); else launchTraceT<true, false, 2>(st, stackClass, sc, rays, n, out, ctr); }
+        else { if (count) launchTraceT<true, true, 1>(st, stackClass, sc, rays, n, out, ctr); else launchTraceT<true, false, 1>(st, stackClass, sc, rays, n, out, ctr); }
+    } else {
+        if (outMode == 0) { if (count) launchTraceT<false, true, 0>(st, stackClass, sc, rays, n, out, ctr); else launchTraceT<false, false, 0>(st, stackClass, sc, rays, n, out, ctr); }
+        else { if (count) launchTraceT<false, true, 1>(st, stackClass, sc, rays, n, out, ctr); else launchTraceT<false, false, 1>(st, stackClass, sc, rays, n, out, ctr); }
+    }
+}
+
+void launchShade(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb) {
+    hipLaunchKernelGGL(kShade, dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, wb);
+}
+
+void launchResolve(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb, float *film, DeviceCounters *ctr) {
+    hipLaunchKernelGGL(kResolve, dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, wb, film, ctr);
+}
+
+} /* namespace kkd */

@@ -1,0 +1,260 @@
+/*
+ * kkd_shade.h -- device-side scene queries of the kk direct path: hit record, sensor rays, emitter
+ * sampling / pdf / evaluation (area, point, environment map).
+ *
+ * Semantics follow the reference (paths relative to /root/reference/src):
+ *   sensors/perspective.cpp:271-298            sampleRayDifferential (differentials are not used on this path)
+ *   skdtree.h fillIntersectionRecord<true> (absent header; behaviour pinned by tests/test_dgeom.cpp:35-120,
+ *     corroborated by librender/skdtree.cpp:164-186), librender/trimesh.cpp:687-747 (uv tangents)
+ *   librender/scene.cpp:828-852, 949-952       sampleEmitterDirect / pdfEmitterDirect
+ *   librender/shape.cpp:99-123, librender/trimesh.cpp:416-427, libcore/triangle.cpp:24-59
+ *   emitters/area.cpp:104-109,158-183 ; emitters/point.cpp:131-151
+ *   emitters/envmap.cpp:358-410, 516-633, 653-658
+ */
+#pragma once
+#include "kkd_types.h"
+#include <hip/hip_fp16.h>
+
+namespace kkd {
+
+struct Its {
+    f3 p, geoN, wi; Frame sh; float t;
+    int shape, material, emitter; uint32_t shapeFlags;
+};
+
+struct DirectRec { f3 ref, refN, p, n, d; float dist, pdf; int measure /* 0 solid angle, 1 discrete */; int emitter; };
+
+__device__ __forceinline__ f3 ldv(const float *base, uint32_t i) { const float *p = base + 3 * (size_t)i; return f3(p[0], p[1], p[2]); }
+
+/* perspective.cpp:271-298 */
+__device__ inline DRay sensorRay(const DSensor &s, float px, float py) {
+    const float x = px * s.invResX, y = py * s.invResY;
+    const float *m = s.s2c;
+    float cx = m[0] * x + m[1] * y + m[3], cy = m[4] * x + m[5] * y + m[7], cz = m[8] * x + m[9] * y + m[11], cw = m[12] * x + m[13] * y + m[15];
+    f3 nearP = (cw == 1.0f) ? f3(cx, cy, cz) : f3(cx, cy, cz) / cw;
+    f3 d = normalize(nearP);
+    const float invZ = 1.0f / d.z;
+    const float *w = s.toWorld;
+    DRay r;
+    r.ox = w[3]; r.oy = w[7]; r.oz = w[11];
+    r.dx = w[0] * d.x + w[1] * d.y + w[2] * d.z;
+    r.dy = w[4] * d.x + w[5] * d.y + w[6] * d.z;
+    r.dz = w[8] * d.x + w[9] * d.y + w[10] * d.z;
+    r.mint = s.nearClip * invZ; r.maxt = s.farClip * invZ;
+    return r;
+}
+
+/* Hit record from (slot, u, v).  full=false skips the shading frame tangents and wi (emitter lookups only
+ * need p / shading normal). */
+template <bool FULL>
+__device__ inline void fillIntersection(const DScene &sc, f3 rayD, const DHit &hit, Its &its) {
+    const float4 *tp = reinterpret_cast<const float4 *>(sc.tris) + (size_t)hit.id * 3;
+    const float4 a = tp[0], b = tp[1], c = tp[2];
+    const uint32_t prim = __float_as_uint(a.w), sh = __float_as_uint(b.w);
+    const DShape shape = sc.shapes[sh];
+    const f3 p0(a.x, a.y, a.z), p1(b.x, b.y, b.z), p2(c.x, c.y, c.z);
+    const float b0 = 1.f - hit.u - hit.v, b1 = hit.u, b2 = hit.v;
+    its.t = hit.t; its.shape = (int)sh; its.material = shape.material; its.emitter = shape.emitter; its.shapeFlags = shape.flags;
+    its.p = p0 * b0 + p1 * b1 + p2 * b2;
+    const f3 side1 = p1 - p0, side2 = p2 - p0;
+    f3 faceNormal = cross(side1, side2);
+    const float len = length(faceNormal);
+    if (len != 0.f) faceNormal = faceNormal / len;
+    uint32_t i0 = 0, i1 = 0, i2 = 0;
+    if (shape.flags & (KKD_SHAPE_HAS_NORMALS | KKD_SHAPE_HAS_TEXCOORDS)) {
+        const uint32_t *ip = sc.indices + 3 * (size_t)prim;
+        i0 = ip[0]; i1 = ip[1]; i2 = ip[2];
+    }
+    f3 n;
+    if (shape.flags & KKD_SHAPE_HAS_NORMALS) {
+        n = normalize(ldv(sc.normals, i0) * b0 + ldv(sc.normals, i1) * b1 + ldv(sc.normals, i2) * b2);
+        if (dot(faceNormal, n) < 0.f) faceNormal = -faceNormal;
+    } else n = faceNormal;
+    its.geoN = faceNormal;
+    its.sh.n = n;
+    if (FULL) {
+        f3 dpdu = side1;
+        if (shape.flags & KKD_SHAPE_HAS_TEXCOORDS) {   /* trimesh.cpp:687-747 */
+            const float *t0 = sc.texcoords + 2 * (size_t)i0, *t1 = sc.texcoords + 2 * (size_t)i1, *t2 = sc.texcoords + 2 * (size_t)i2;
+            const float du1 = t1[0] - t0[0], dv1 = t1[1] - t0[1], du2 = t2[0] - t0[0], dv2 = t2[1] - t0[1];
+            const float det = du1 * dv2 - dv1 * du2;
+            if (len == 0.f) dpdu = f3(0.f);
+            else if (det == 0.f) { f3 tv; coordinateSystem(cross(side1, side2) / len, dpdu, tv); }
+            else dpdu = (side1 * dv2 - side2 * dv1) * (1.0f / det);
+        }
+        its.sh.s = normalize(dpdu - n * dot(n, dpdu));
+        its.sh.t = cross(n, its.sh.s);
+        its.wi = its.sh.toLocal(-rayD);
+    }
+}
+
+/* pmf.h DiscreteDistribution::sample: lower_bound over n+1 entries, skip zero-probability entries */
+__device__ inline uint32_t cdfSample(const float *cdf, uint32_t n, float v) {
+    uint32_t lo = 0, cnt = n + 1;
+    while (cnt > 0) {
+        const uint32_t step = cnt >> 1, mid = lo + step;
+        if (cdf[mid] < v) { lo = mid + 1; cnt -= step + 1; } else cnt = step;
+    }
+    uint32_t index = lo > 0 ? lo - 1 : 0;
+    index = min(index, n - 1);
+    while (index + 1 < n && cdf[index + 1] - cdf[index] == 0.f) ++index;
+    return index;
+}
+__device__ inline uint32_t cdfSampleReuse(const float *cdf, uint32_t n, float &v, float &pdf) {
+    const uint32_t index = cdfSample(cdf, n, v);
+    const float c0 = cdf[index], c1 = cdf[index + 1];
+    pdf = c1 - c0;
+    v = (v - c0) / (c1 - c0);
+    return index;
+}
+/* envmap.cpp:653-658 */
+__device__ inline uint32_t envSampleReuse(const float *cdf, uint32_t size, float &sample) {
+    uint32_t lo = 0, cnt = size + 1;
+    while (cnt > 0) {
+        const uint32_t step = cnt >> 1, mid = lo + step;
+        if (cdf[mid] < sample) { lo = mid + 1; cnt -= step + 1; } else cnt = step;
+    }
+    const uint32_t index = min(lo > 0 ? lo - 1 : 0u, size - 1);
+    const float c0 = cdf[index], c1 = cdf[index + 1];
+    sample = (sample - c0) / (c1 - c0);
+    return index;
+}
+
+__device__ __forceinline__ f3 rot3(const float *R, f3 v) {
+    return f3(R[0] * v.x + R[1] * v.y + R[2] * v.z, R[3] * v.x + R[4] * v.y + R[5] * v.z, R[6] * v.x + R[7] * v.y + R[8] * v.z);
+}
+/* mipmap.h evalTexel: repeat in U, clamp in V (envmap.cpp:145-146); texels are stored as half */
+__device__ inline f3 envTexel(const DEnvMap &e, int x, int y) {
+    x = x % e.w; if (x < 0) x += e.w;
+    y = min(max(y, 0), e.h - 1);
+    const uint2 raw = reinterpret_cast<const uint2 *>(e.texels)[(size_t)y * e.w + x];
+    const __half2 rg = *reinterpret_cast<const __half2 *>(&raw.x), ba = *reinterpret_cast<const __half2 *>(&raw.y);
+    const float2 frg = __half22float2(rg), fba = __half22float2(ba);
+    return f3(frg.x, frg.y, fba.x);
+}
+__device__ inline void envBilinearRows(const DEnvMap &e, float u, float v, f3 &value1, f3 &value2, int &yPos) {
+    const int xPos = (int)floorf(u); yPos = (int)floorf(v);
+    const float dx1 = u - xPos, dx2 = 1.0f - dx1, dy1 = v - yPos, dy2 = 1.0f - dy1;
+    value1 = envTexel(e, xPos, yPos) * dx2 * dy2 + envTexel(e, xPos + 1, yPos) * dx1 * dy2;
+    value2 = envTexel(e, xPos, yPos + 1) * dx2 * dy1 + envTexel(e, xPos + 1, yPos + 1) * dx1 * dy1;
+}
+/* envmap.cpp:380-393,408-409 without ray differentials: bilinear level-0 lookup */
+__device__ inline f3 envEval(const DEnvMap &e, f3 worldDir) {
+    const f3 v = rot3(e.toLocal, worldDir);
+    const float uu = atan2f(v.x, -v.z) * kInvTwoPi, vv = safeAcos(v.y) * kInvPi;
+    if (!isfinite(uu) || !isfinite(vv)) return f3(0.f);
+    f3 a, b; int yPos;
+    envBilinearRows(e, uu * e.w - 0.5f, vv * e.h - 0.5f, a, b, yPos);
+    return (a + b) * e.scale;
+}
+/* envmap.cpp:603-633 */
+__device__ inline float envPdfDirection(const DEnvMap &e, f3 d) {
+    const float uu = atan2f(d.x, -d.z) * kInvTwoPi, vv = safeAcos(d.y) * kInvPi;
+    if (!isfinite(uu) || !isfinite(vv)) return 0.f;
+    f3 a, b; int yPos;
+    envBilinearRows(e, uu * e.w - 0.5f, vv * e.h - 0.5f, a, b, yPos);
+    const float sinTheta = safeSqrt(1.f - d.y * d.y);
+    return (luminance(a) * e.rowWeights[min(max(yPos, 0), e.h - 1)] + luminance(b) * e.rowWeights[min(max(yPos + 1, 0), e.h - 1)])
+           * e.normalization / fmaxf(fabsf(sinTheta), kEpsilon);
+}
+/* envmap.cpp:567-600 */
+__device__ inline void envSampleDirection(const DEnvMap &e, f2 sample, f3 &d, f3 &value, float &pdf) {
+    const uint32_t row = envSampleReuse(e.cdfRows, (uint32_t)e.h, sample.y);
+    const uint32_t col = envSampleReuse(e.cdfCols + (size_t)row * (e.w + 1), (uint32_t)e.w, sample.x);
+    const float px = (float)col + intervalToTent(sample.x), py = (float)row + intervalToTent(sample.y);
+    f3 a, b; int yPos;
+    envBilinearRows(e, px, py, a, b, yPos);
+    value = (a + b) * e.scale;
+    pdf = (luminance(a) * e.rowWeights[min(max(yPos, 0), e.h - 1)] + luminance(b) * e.rowWeights[min(max(yPos + 1, 0), e.h - 1)]) * e.normalization;
+    float sinPhi, cosPhi, sinTheta, cosTheta;
+    sincosf(e.pixelSizeX * (px + 0.5f), &sinPhi, &cosPhi);
+    sincosf(e.pixelSizeY * (py + 0.5f), &sinTheta, &cosTheta);
+    d = f3(sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta);
+    pdf /= fmaxf(fabsf(sinTheta), kEpsilon);
+}
+
+/* area.cpp:104-109 */
+__device__ __forceinline__ f3 areaEval(const DEmitter &e, f3 shN, f3 d) {
+    if (dot(shN, d) <= 0.f) return f3(0.f);
+    return f3(e.radiance[0], e.radiance[1], e.radiance[2]);
+}
+
+/* Scene::sampleEmitterDirect WITHOUT the visibility test (the shadow ray is queued by the caller):
+ * returns value = Le / pdf with pdf including the emitter-selection probability; zero if not sampleable. */
+__device__ inline f3 sampleEmitterDirectUnoccluded(const DScene &sc, DirectRec &dRec, f2 sample) {
+    float emPdf;
+    const uint32_t index = cdfSampleReuse(sc.emitterCdf, sc.nEmitters, sample.x, emPdf);
+    const DEmitter e = sc.emitters[index];
+    f3 value(0.f);
+    dRec.pdf = 0.f;
+    if (e.type == KKD_EMITTER_AREA) {
+        float dummy;
+        const uint32_t local = cdfSampleReuse(sc.areaCdf + e.cdfOffset, e.nPrims, sample.y, dummy);
+        const uint32_t prim = e.firstPrim + local;
+        const uint32_t *ip = sc.indices + 3 * (size_t)prim;
+        const uint32_t i0 = ip[0], i1 = ip[1], i2 = ip[2];
+        const f3 p0 = ldv(sc.positions, i0), p1 = ldv(sc.positions, i1), p2 = ldv(sc.positions, i2);
+        const f2 bary = squareToUniformTriangle(sample);
+        const f3 sideA = p1 - p0, sideB = p2 - p0;
+        dRec.p = p0 + (sideA * bary.x) + (sideB * bary.y);
+        if (e.shapeFlags & KKD_SHAPE_HAS_NORMALS)
+            dRec.n = normalize(ldv(sc.normals, i0) * (1.0f - bary.x - bary.y) + ldv(sc.normals, i1) * bary.x + ldv(sc.normals, i2) * bary.y);
+        else
+            dRec.n = normalize(cross(sideA, sideB));
+        dRec.pdf = e.invArea;
+        dRec.d = dRec.p - dRec.ref;
+        const float distSquared = dot(dRec.d, dRec.d);
+        dRec.dist = sqrtf(distSquared);
+        dRec.d = dRec.d / dRec.dist;
+        const float dp = fabsf(dot(dRec.d, dRec.n));
+        dRec.pdf *= dp != 0.f ? (distSquared / dp) : 0.0f;
+        dRec.measure = 0;
+        if (dot(dRec.d, dRec.refN) >= 0.f && dot(dRec.d, dRec.n) < 0.f && dRec.pdf != 0.f)
+            value = f3(e.radiance[0], e.radiance[1], e.radiance[2]) / dRec.pdf;
+        else dRec.pdf = 0.0f;
+    } else if (e.type == KKD_EMITTER_POINT) {
+        dRec.p = f3(e.position[0], e.position[1], e.position[2]); dRec.pdf = 1.0f; dRec.measure = 1;
+        dRec.d = dRec.p - dRec.ref;
+        dRec.dist = length(dRec.d);
+        const float invDist = 1.0f / dRec.dist;
+        dRec.d = dRec.d * invDist;
+        dRec.n = f3(0.f);
+        value = f3(e.radiance[0], e.radiance[1], e.radiance[2]) * (invDist * invDist);
+    } else {
+        f3 d, v; float pdf;
+        envSampleDirection(sc.env, sample, d, v, pdf);
+        const f3 wd = rot3(sc.env.toWorld, d);
+        const f3 center(sc.env.center[0], sc.env.center[1], sc.env.center[2]);
+        float nearT, farT;
+        if (isZero(v) || pdf == 0.f || !sphereRayIntersect(center, sc.env.radius, dRec.ref, wd, nearT, farT) || nearT >= 0.f || farT <= 0.f) {
+            dRec.pdf = 0.0f;
+        } else {
+            dRec.pdf = pdf; dRec.p = dRec.ref + wd * farT; dRec.n = normalize(center - dRec.p);
+            dRec.dist = farT; dRec.d = wd; dRec.measure = 0;
+            value = v / pdf;
+        }
+    }
+    if (dRec.pdf != 0.f) {
+        dRec.emitter = (int)index;
+        dRec.pdf *= emPdf;
+        return value / emPdf;
+    }
+    return f3(0.f);
+}
+
+/* scene.cpp:949-952 */
+__device__ inline float pdfEmitterDirect(const DScene &sc, const DirectRec &dRec) {
+    const DEmitter e = sc.emitters[dRec.emitter];
+    float pdf = 0.f;
+    if (e.type == KKD_EMITTER_AREA) {
+        if (dot(dRec.d, dRec.refN) >= 0.f && dot(dRec.d, dRec.n) < 0.f)
+            pdf = e.invArea * (dRec.dist * dRec.dist) / fabsf(dot(dRec.d, dRec.n));
+    } else if (e.type == KKD_EMITTER_POINT) {
+        pdf = dRec.measure == 1 ? 1.0f : 0.0f;
+    } else {
+        pdf = envPdfDirection(sc.env, rot3(sc.env.toLocal, dRec.d));
+    }
+    return pdf * (e.weight * sc.emitterNormalization);
+}
+
+} /* namespace kkd */

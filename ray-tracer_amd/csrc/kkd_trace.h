@@ -1,0 +1,154 @@
+/*
+ * kkd_trace.h -- gfx950 ray traversal: one ray per lane, 4-wide BVH, per-lane stack in LDS,
+ * watertight triangle test (Woop, Benthin, Wald 2013).
+ *
+ * Replaces ShapeKDTree::rayIntersect(ray, its) / rayIntersect(ray) of the reference
+ * (src/librender/skdtree.cpp:112-142, 207-226: AABB clip, adaptive ray epsilon, Havran kd-tree walk,
+ * TriAccel projection test).  Kept from the reference: the adaptive epsilon rule, the [mint, maxt]
+ * acceptance interval, the hit record (t, barycentrics of vertices 1 and 2, primitive).
+ *
+ * Memory shape: a node visit is eight 16-byte loads of one 128-byte line (Node4), a triangle test is
+ * three 16-byte loads (LeafTri); the stack never leaves LDS (index = slot * BLOCK + thread, so the
+ * two 32-lane halves of a wave never collide on a bank).
+ */
+#pragma once
+#include "kkd_types.h"
+
+namespace kkd {
+
+struct TraceCounters { unsigned long long rays, nodes, tris; };
+
+__device__ __forceinline__ float selc(float x, float y, float z, int k) { return k == 0 ? x : (k == 1 ? y : z); }
+
+/* Per-ray constants of the watertight test */
+struct WoopRay {
+    int kx, ky, kz; float Sx, Sy, Sz;
+    __device__ __forceinline__ void init(float dx, float dy, float dz) {
+        const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
+        kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
+        kx = kz + 1; if (kx == 3) kx = 0;
+        ky = kx + 1; if (ky == 3) ky = 0;
+        const float dkz = selc(dx, dy, dz, kz);
+        if (dkz < 0.0f) { int t = kx; kx = ky; ky = t; }
+        Sx = selc(dx, dy, dz, kx) / dkz;
+        Sy = selc(dx, dy, dz, ky) / dkz;
+        Sz = 1.0f / dkz;
+    }
+};
+
+/* returns true and updates (t,u,v) if the triangle is hit with tmin <= t <= tmax.
+ * No fused multiply-adds in the edge functions: shared edges must evaluate to exact negatives. */
+__device__ __forceinline__ bool woopIntersect(const WoopRay &w, float ox, float oy, float oz,
+                                              const float4 &a, const float4 &b, const float4 &c,
+                                              float tmin, float tmax, float &tOut, float &uOut, float &vOut) {
+    const float Ax0 = a.x - ox, Ay0 = a.y - oy, Az0 = a.z - oz;
+    const float Bx0 = b.x - ox, By0 = b.y - oy, Bz0 = b.z - oz;
+    const float Cx0 = c.x - ox, Cy0 = c.y - oy, Cz0 = c.z - oz;
+    const float Akz = selc(Ax0, Ay0, Az0, w.kz), Bkz = selc(Bx0, By0, Bz0, w.kz), Ckz = selc(Cx0, Cy0, Cz0, w.kz);
+    const float Ax = __fsub_rn(selc(Ax0, Ay0, Az0, w.kx), __fmul_rn(w.Sx, Akz));
+    const float Ay = __fsub_rn(selc(Ax0, Ay0, Az0, w.ky), __fmul_rn(w.Sy, Akz));
+    const float Bx = __fsub_rn(selc(Bx0, By0, Bz0, w.kx), __fmul_rn(w.Sx, Bkz));
+    const float By = __fsub_rn(selc(Bx0, By0, Bz0, w.ky), __fmul_rn(w.Sy, Bkz));
+    const float Cx = __fsub_rn(selc(Cx0, Cy0, Cz0, w.kx), __fmul_rn(w.Sx, Ckz));
+    const float Cy = __fsub_rn(selc(Cx0, Cy0, Cz0, w.ky), __fmul_rn(w.Sy, Ckz));
+    float U = __fsub_rn(__fmul_rn(Cx, By), __fmul_rn(Cy, Bx));
+    float V = __fsub_rn(__fmul_rn(Ax, Cy), __fmul_rn(Ay, Cx));
+    float W = __fsub_rn(__fmul_rn(Bx, Ay), __fmul_rn(By, Ax));
+    if (U == 0.0f || V == 0.0f || W == 0.0f) {
+        U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+        V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+        W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+    }
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+    const float det = U + V + W;
+    if (det == 0.0f) return false;
+    const float T = U * (w.Sz * Akz) + V * (w.Sz * Bkz) + W * (w.Sz * Ckz);
+    const float rcp = 1.0f / det;
+    const float t = T * rcp;
+    if (!(t >= tmin && t <= tmax)) return false;
+    tOut = t; uOut = V * rcp; vOut = W * rcp;
+    return true;
+}
+
+/* adaptive ray epsilon, skdtree.cpp:126-129 (closest hit) and :213-214 (shadow rays: no inner clamp) */
+template <bool ANY> __device__ __forceinline__ float adaptiveMinT(float mint, float ox, float oy, float oz) {
+    if (mint == kEpsilon) {
+        float m = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
+        if (!ANY) m = fmaxf(m, kEpsilon);
+        mint *= m;
+    }
+    return mint;
+}
+
+/*
+ * ANY      : stop at the first hit (ShapeKDTree::rayIntersect(ray)); else closest hit.
+ * COUNT    : accumulate visited nodes / tested triangles (the N_nodes, N_tris of the roofline formula).
+ * Returns hit.id = LeafTri slot or kNoHit.
+ */
+template <bool ANY, bool COUNT, int STACK, int BLOCK>
+__device__ __forceinline__ DHit traverse(const Node4 *__restrict__ nodes, const LeafTri *__restrict__ tris,
+                                         const DRay &ray, uint32_t *sstack, uint32_t &nNodes, uint32_t &nTris) {
+    DHit hit; hit.t = kInf; hit.u = 0.f; hit.v = 0.f; hit.id = kNoHit;
+    const float ox = ray.ox, oy = ray.oy, oz = ray.oz;
+    const float tmin = adaptiveMinT<ANY>(ray.mint, ox, oy, oz);
+    float tmax = ray.maxt;
+    if (!(tmax > tmin)) return hit;
+    const float idx = 1.0f / ray.dx, idy = 1.0f / ray.dy, idz = 1.0f / ray.dz;
+    WoopRay wr; wr.init(ray.dx, ray.dy, ray.dz);
+    const float4 *nodes4 = reinterpret_cast<const float4 *>(nodes);
+    const float4 *tris4 = reinterpret_cast<const float4 *>(tris);
+    const int tid = threadIdx.x;
+    int sp = 0;
+    uint32_t cur = 0;   /* root */
+    /* every wave leaves this loop: the walk is finite on a tree, and the step bound ends it on a malformed one */
+    for (int guard = 1 << 24; guard > 0; --guard) {
+        if (!(cur & kLeafBit)) {
+            if (COUNT) ++nNodes;
+            const float4 *n = nodes4 + (size_t)cur * 8;
+            const float4 mnx = n[0], mny = n[1], mnz = n[2], mxx = n[3], mxy = n[4], mxz = n[5];
+            const uint4 ch = *reinterpret_cast<const uint4 *>(n + 6);
+            float d0, d1, d2, d3;
+#define KKD_SLAB(D, LX, LY, LZ, HX, HY, HZ) { \
+            const float tx0 = (LX - ox) * idx, tx1 = (HX - ox) * idx; \
+            const float ty0 = (LY - oy) * idy, ty1 = (HY - oy) * idy; \
+            const float tz0 = (LZ - oz) * idz, tz1 = (HZ - oz) * idz; \
+            const float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin)); \
+            const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tmax)) * 1.0000004f; \
+            D = (tn <= tf) ? tn : kInf; }
+            KKD_SLAB(d0, mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x)
+            KKD_SLAB(d1, mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y)
+            KKD_SLAB(d2, mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z)
+            KKD_SLAB(d3, mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w)
+#undef KKD_SLAB
+            uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+#define KKD_CSWAP(DA, CA, DB, CB) { const bool s = DB < DA; const float td = s ? DB : DA; DB = s ? DA : DB; DA = td; \
+                                    const uint32_t tc = s ? CB : CA; CB = s ? CA : CB; CA = tc; }
+            KKD_CSWAP(d0, c0, d1, c1) KKD_CSWAP(d2, c2, d3, c3) KKD_CSWAP(d0, c0, d2, c2) KKD_CSWAP(d1, c1, d3, c3) KKD_CSWAP(d1, c1, d2, c2)
+#undef KKD_CSWAP
+            if (d0 < kInf) {
+                if (d3 < kInf) sstack[(sp++) * BLOCK + tid] = c3;
+                if (d2 < kInf) sstack[(sp++) * BLOCK + tid] = c2;
+                if (d1 < kInf) sstack[(sp++) * BLOCK + tid] = c1;
+                cur = c0;
+                continue;
+            }
+        } else {
+            const uint32_t start = cur & kLeafStartMask, cnt = ((cur >> 28) & 7u) + 1u;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                if (COUNT) ++nTris;
+                const float4 *tp = tris4 + (size_t)(start + i) * 3;
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+                float t, u, v;
+                if (woopIntersect(wr, ox, oy, oz, a, b, c, tmin, tmax, t, u, v)) {
+                    tmax = t; hit.t = t; hit.u = u; hit.v = v; hit.id = start + i;
+                    if (ANY) return hit;
+                }
+            }
+        }
+        if (sp == 0) break;
+        cur = sstack[(--sp) * BLOCK + tid];
+    }
+    return hit;
+}
+
+} /* namespace kkd */

@@ -1,0 +1,105 @@
+/*
+ * kkd_types.h -- layout of the GPU-resident scene of libkkdirect (HBM-resident, read-only during a
+ * render) and of the wavefront work buffers.  Shared by the host builders and the gfx950 kernels.
+ *
+ * Reference types these replace (paths relative to /root/reference/src):
+ *   KDNode + m_indices + TriAccel table (librender/skdtree.cpp:68-110)  -> Node4 + LeafTri
+ *   BSDF plugin state (bsdfs/*.cpp serialize())                        -> DMaterial
+ *   Emitter plugin state + Scene::m_emitterPDF (librender/scene.cpp:376-380) -> DEmitter + emitterCdf
+ *   EnvironmentMap tables (emitters/envmap.cpp:260-329)                -> DEnvMap
+ *   PerspectiveCameraImpl (sensors/perspective.cpp:126-180)            -> DSensor
+ *   ReconstructionFilter table (libcore/rfilter.cpp:37-55)             -> DFilter
+ */
+#pragma once
+#include "kkd_math.h"
+#include "../../include/kkdirect.h"
+
+namespace kkd {
+
+/* ---- acceleration structure -------------------------------------------------------------------
+ * 4-wide BVH, one 128-byte node = one L2 line: child boxes in SoA so a lane tests the four boxes
+ * with eight 16-byte loads.  child[i]: bit31 set = leaf, bits 28..30 = triangle count - 1,
+ * bits 0..27 = first LeafTri slot; otherwise index of the child node.  Unused children have
+ * min = max = +inf and child = 0 -- no ray can enter them. */
+struct alignas(128) Node4 {
+    float minx[4], miny[4], minz[4];
+    float maxx[4], maxy[4], maxz[4];
+    uint32_t child[4];
+    uint32_t pad[4];
+};
+static constexpr uint32_t kLeafBit = 0x80000000u;
+static constexpr uint32_t kLeafStartMask = 0x0FFFFFFFu;
+static constexpr int kMaxLeafTris = 4;
+
+/* Triangles in leaf order, 48 bytes: three 16-byte loads.  w components carry ids (bit patterns). */
+struct alignas(16) LeafTri {
+    float v0x, v0y, v0z; uint32_t prim;   /* global primitive id = first_prim + primIndex          */
+    float v1x, v1y, v1z; uint32_t shape;  /* shape index (ShapeKDTree::addShape order)              */
+    float v2x, v2y, v2z; uint32_t pad;
+};
+
+/* ---- BSDF::EBSDFType bits used on this path (names follow the reference's bsdf.h) ---- */
+enum : uint32_t {
+    EDiffuseReflection = 0x0004, EGlossyReflection = 0x0010, EDeltaReflection = 0x0040,
+    EDeltaTransmission = 0x0080, EFrontSide = 0x1000, EBackSide = 0x2000,
+    EDelta = EDeltaReflection | EDeltaTransmission, ETransmission = EDeltaTransmission
+};
+
+struct DMaterial {          /* 128 bytes */
+    int32_t type, distr, sampleVisible, nonlinear;
+    int32_t nested0, nested1; uint32_t typeFlags; int32_t tableOffset; /* into rtTables: 100 floats T12(cos) */
+    float alphaU, alphaV, eta, invEta2;
+    float specSamplingWeight, fdr /* 1 - diffuse transmittance of the inside table */, pad0, pad1;
+    float refl[3], specRefl[3], specTrans[3], condEta[3], condK[3];
+    float pad2;
+};
+
+struct DShape {             /* 32 bytes */
+    uint32_t firstPrim, nPrims; int32_t material, emitter; uint32_t flags; uint32_t pad[3];
+};
+
+struct DEmitter {           /* 64 bytes */
+    int32_t type, shape; float weight, invArea;
+    float radiance[3]; uint32_t cdfOffset;     /* area: offset of the shape's (nPrims+1)-entry area CDF in areaCdf */
+    float position[3]; uint32_t firstPrim;
+    uint32_t nPrims, shapeFlags, pad[2];
+};
+
+struct DEnvMap {
+    int32_t w, h; float scale, normalization;
+    float toWorld[9], toLocal[9];
+    float center[3], radius;
+    float pixelSizeX, pixelSizeY;
+    const uint32_t *texels;    /* w*h texels, 2 words each: RGBA half (A unused)             */
+    const float *cdfRows;      /* h+1                                                        */
+    const float *cdfCols;      /* (w+1)*h                                                    */
+    const float *rowWeights;   /* h                                                          */
+};
+
+struct DSensor {
+    float toWorld[12];         /* rows of the affine camera-to-world matrix                   */
+    float s2c[16];             /* sampleToCamera, full projective 4x4                         */
+    float nearClip, farClip, invResX, invResY;
+    int32_t cropW, cropH, filmHasAlpha, pad;
+};
+
+struct DFilter { float values[32]; float radius, scaleFactor; int32_t border, pad; };
+
+struct DScene {
+    const Node4 *nodes; const LeafTri *tris;
+    const float *positions; const float *normals; const float *texcoords; const uint32_t *indices;
+    const DShape *shapes; const DMaterial *materials; const DEmitter *emitters;
+    const float *emitterCdf;   /* nEmitters+1                                                 */
+    const float *areaCdf;      /* concatenated per-emitter-shape triangle area CDFs            */
+    const float *rtTables;     /* rough-transmittance tables, 100 floats each                  */
+    uint32_t nShapes, nMaterials, nEmitters; int32_t envEmitter;
+    float emitterNormalization; float pad[3];
+    DEnvMap env; DSensor sensor; DFilter filter;
+};
+
+/* ---- wavefront buffers ---- */
+struct alignas(16) DRay { float ox, oy, oz, mint, dx, dy, dz, maxt; };     /* 32 bytes = the C ABI ray  */
+struct alignas(16) DHit { float t, u, v; uint32_t id; };                   /* id: LeafTri slot (internal) or prim id (ABI) */
+static constexpr uint32_t kNoHit = 0xFFFFFFFFu;
+
+} /* namespace kkd */
