@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the kk direct-lighting path on MI355X (BASELINE.json metric: Msamples/s and
+Mrays/s, fraction of the HBM roofline, CPU baseline beside it).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+One step = one full render pass of the workload (default C2 of BASELINE.json: Sponza-class interior,
+~260k triangles, 1920x1080, 256 spp, bsdfSamples = lightSamples = 1).  With N ranks the image tiles are
+sharded round-robin over the ranks (tile_index = rank, tile_count = N, no collective while rendering)
+and every rank renders N x 256 spp of its tiles, so per-GPU work is constant (weak scaling); the films
+are merged by one RCCL sum-reduce per step (what Film::put(block) does in the reference), inside the
+timed region.  --split sample renders the whole frame on every rank with disjoint sample ranges instead.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "ray-tracer_amd"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def make_workload(name, scale):
+    from kkdirect import scenes
+    if name == "c1":
+        return scenes.cornell_box(512, 512), 64, "C1 Cornell box 512x512 64spp"
+    if name == "c2":
+        w, h = int(1920 * scale), int(1080 * scale)
+        return scenes.sponza_class(w, h), 256, "C2 Sponza-class interior ~260k tris %dx%d 256spp" % (w, h)
+    if name == "c3":
+        w, h = int(1920 * scale), int(1080 * scale)
+        return scenes.many_lights(w, h), 128, "C3 many-light 10k emitters %dx%d 128spp" % (w, h)
+    if name == "c4":
+        w, h = int(3840 * scale), int(2160 * scale)
+        return scenes.scanned_mesh(w, h), 512, "C4 10.5M-tri mesh + HDR envmap %dx%d 512spp" % (w, h)
+    raise SystemExit("unknown workload " + name)
+
+
+def stage_bytes(st, n_b, n_l, per_ray):
+    """Algorithmic bytes per kernel stage for one render ('algorithmic bytes').
+    per_ray[k] = (nodes/ray, tris/ray) measured by the counting build of the same traversal."""
+    rays = list(st.class_rays)
+    io = (16.0, 48.0, 36.0)   # primary: hit write; bsdf: ray read + hit write; shadow: ray read + flag write
+    trav = [rays[k] * (io[k] + per_ray[k][0] * 128.0 + per_ray[k][1] * 48.0) for k in range(3)]
+    s = float(st.samples)
+    shade = s * (16 + 48 + 12 + 36 + 32 + 128 + 64 + 12 + 36 + 16 + 16 + n_b * 48 + n_l * 48)
+    resolve = s * (16 + 16 + n_b * 64 + n_l * 20 + 125.0 / 64.0 * 8.0)
+    return [trav[0], shade, trav[1], trav[2], resolve]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4"])
+    ap.add_argument("--split", default="tile", choices=["tile", "sample"])
+    ap.add_argument("--spp", type=int, default=0, help="override the workload's spp (then the line is not the headline config)")
+    ap.add_argument("--scale", type=float, default=1.0, help="resolution scale (debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=0, help="camera samples in flight per batch (0 = library default)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    import torch
+    import kkdirect
+    from kkdirect import abi
+    if not torch.cuda.is_available() or kkdirect.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: libkkdirect has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    scene, spp, label = make_workload(args.workload, args.scale)
+    if args.spp:
+        spp = args.spp
+    n_b = n_l = 1
+    t0 = time.perf_counter()
+    ctx = kkdirect.Context(device=local_rank, seed=1, max_samples_in_flight=args.batch).upload(scene)
+    upload_s = time.perf_counter() - t0
+    W, H = ctx.width, ctx.height
+    film = torch.zeros(H * W * 5, dtype=torch.float32, device="cuda")
+
+    if args.split == "tile":
+        kw = dict(spp=spp * world, tile_index=rank, tile_count=world, sample_first=0)
+    else:
+        kw = dict(spp=spp, tile_index=0, tile_count=1, sample_first=rank * spp)
+
+    def step():
+        st = ctx.render_device(film.data_ptr(), bsdf_samples=n_b, light_samples=n_l, **kw)
+        if dist is not None:
+            dist.reduce(film, dst=0)      # film merge = Film::put(block): sum of per-rank films
+        return st
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    stats = [step() for _ in range(args.steps)]
+    fence()
+    elapsed = time.perf_counter() - t0
+    samples = sum(s.samples for s in stats)
+    rays = sum(s.rays_closest + s.rays_shadow for s in stats)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([samples, rays], dtype=torch.float64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        samples, rays = float(c[0].item()), float(c[1].item())
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: HIP-event stage times of the timed steps (recorded by the library on
+        # the stream its kernels run on) against algorithmic bytes from a counting pass of the same traversal ----
+        cctx = kkdirect.Context(device=local_rank, seed=1, count_traversal=True).upload(scene)
+        _, cst = cctx.render(min(spp, 8), n_b, n_l, tile_index=kw["tile_index"], tile_count=kw["tile_count"])
+        cctx.close()
+        per_ray = [(cst.class_nodes[k] / max(1, cst.class_rays[k]), cst.class_tris[k] / max(1, cst.class_rays[k])) for k in range(3)]
+        stage_s = [sum(s.stage_seconds[k] for s in stats) for k in range(5)]
+        stage_n = [sum(s.stage_launches[k] for s in stats) for k in range(5)]
+        bytes_k = [sum(stage_bytes(s, n_b, n_l, per_ray)[k] for s in stats) for k in range(5)]
+        dom = int(np.argmax(stage_s))
+        avg_launch_s = stage_s[dom] / max(1, stage_n[dom])
+        achieved = bytes_k[dom] / max(1, stage_n[dom]) / max(avg_launch_s, 1e-12) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload, {}).get(abi.STAGE_NAMES[dom])
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": abi.STAGE_NAMES[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": stage_n[dom],
+                    "algorithmic_bytes_per_launch": round(bytes_k[dom] / max(1, stage_n[dom])),
+                    "nodes_per_ray": [round(p[0], 2) for p in per_ray], "tris_per_ray": [round(p[1], 2) for p in per_ray],
+                    "stage_ms_per_step": {abi.STAGE_NAMES[k]: round(stage_s[k] / args.steps * 1e3, 3) for k in range(5)}}
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(scene, n_b, n_l, W, H)
+        out = {
+            "metric": "Msamples/s (kk direct integrator)", "value": round(samples / elapsed / 1e6, 3), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "mrays_per_s": round(rays / elapsed / 1e6, 3),
+            "config": {"workload": label, "spp_total": kw["spp"] if args.split == "tile" else spp * world, "bsdfSamples": n_b, "lightSamples": n_l,
+                       "split": args.split, "triangles": int(scene._nt), "scene_upload_s": round(upload_s, 2)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(scene, n_b, n_l, W, H):
+    """The oracle (CPU restatement of the reference path: SAH kd-tree + TriAccel + Havran + kk Li, 32x32 tiles,
+    one thread per core) timed on a bounded sample of the same workload: the full frame at a low spp."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import kkoracle
+    cores = min(16, os.cpu_count() or 1)
+    o = kkoracle.Oracle(scene)
+    _, s1 = o.render(1, n_b, n_l, threads=cores)
+    spp = int(max(1, min(64, 12.0 / max(s1.seconds, 1e-3))))
+    _, st = o.render(spp, n_b, n_l, threads=cores)
+    return {"value": round(st.samples / st.seconds / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "mrays_per_s": round((st.rays_closest + st.rays_shadow) / st.seconds / 1e6, 3),
+            "sample": "same scene and resolution (%dx%d) at %d spp instead of the workload's spp, %.1f s of CPU time" % (W, H, spp, st.seconds)}
+
+
+if __name__ == "__main__":
+    main()

@@ -71,10 +71,6 @@ extern "C" {
 #define KKD_SHAPE_HAS_NORMALS   1u  /* per-vertex normals valid for this shape (TriMesh::m_normals != NULL) */
 #define KKD_SHAPE_HAS_TEXCOORDS 2u  /* per-vertex uv valid (TriMesh::m_texcoords != NULL)                   */
 
-/* multi-GPU split mode */
-#define KKD_SPLIT_TILE   0
-#define KKD_SPLIT_SAMPLE 1
-
 /* ---- scene description ------------------------------------------------------------ */
 
 /* One Mitsuba Shape after Scene::addShape expansion (src/librender/scene.cpp:558-591); the
@@ -162,9 +158,11 @@ typedef struct kkd_scene_desc {
 
 /* ---- context / render parameters ----------------------------------------------------- */
 
+#define KKD_FLAG_COUNT_TRAVERSAL 1u  /* count visited nodes / tested triangles in every traversal (measurement runs) */
+
 typedef struct kkd_config {
     int32_t  device;           /* HIP device ordinal                                           */
-    int32_t  split_mode;       /* KKD_SPLIT_*; informational (the caller shards, see kkd_render_params) */
+    uint32_t flags;            /* KKD_FLAG_*                                                   */
     uint64_t seed;             /* RNG seed: key = (seed, pixel), counter = (sample, dimension) */
     uint64_t max_samples_in_flight; /* 0 = library default; bounds the wavefront buffers       */
 } kkd_config;
@@ -183,15 +181,30 @@ typedef struct kkd_render_params {
     uint32_t sample_first;     /* first RNG sample index (0)                                   */
 } kkd_render_params;
 
+/* ray classes / kernel stages of one render (indices of the arrays in kkd_stats) */
+#define KKD_RAYS_PRIMARY 0   /* sensor rays, closest hit   (kernel kPrimary)                      */
+#define KKD_RAYS_BSDF    1   /* BSDF-sampled rays, closest hit (kernel kTrace<closest>)           */
+#define KKD_RAYS_SHADOW  2   /* emitter-sampled rays, any hit  (kernel kTrace<any>)               */
+#define KKD_STAGE_PRIMARY 0
+#define KKD_STAGE_SHADE   1
+#define KKD_STAGE_BSDF    2
+#define KKD_STAGE_SHADOW  3
+#define KKD_STAGE_RESOLVE 4
+
 typedef struct kkd_stats {
     uint64_t samples;          /* camera samples processed                                     */
     uint64_t rays_closest;     /* "Normal rays traced"  (skdtree.cpp:46,123)                    */
     uint64_t rays_shadow;      /* "Shadow rays traced"  (skdtree.cpp:47,151,210)                */
-    double   seconds;          /* device time of the render loop (HIP events)                  */
+    double   seconds;          /* device time of the render loop (HIP events on the context's stream) */
     double   seconds_trace;    /* part of it spent in the traversal kernels                    */
-    double   algorithmic_bytes;/* sum over rays of B_ray + B_shade + B_splat        */
-    uint64_t nodes_visited;    /* filled when KKD_COUNT_TRAVERSAL is requested via kkd_trace_counted */
+    double   algorithmic_bytes;/* SURVEY 8d, traversal kernels: sum over rays of B_ray (0 unless traversal counting is on) */
+    uint64_t nodes_visited;    /* totals of the per-class counters below                        */
     uint64_t tris_tested;
+    uint64_t class_rays[3];    /* rays actually traced per class (KKD_RAYS_*)                   */
+    uint64_t class_nodes[3];   /* BVH nodes visited per class   (only with KKD_FLAG_COUNT_TRAVERSAL) */
+    uint64_t class_tris[3];    /* triangles tested per class    (only with KKD_FLAG_COUNT_TRAVERSAL) */
+    double   stage_seconds[5]; /* device time per kernel stage (KKD_STAGE_*), summed over launches */
+    uint64_t stage_launches[5];
 } kkd_stats;
 
 typedef struct kkd_hit {       /* IntersectionCache of skdtree.h: {shapeIndex, primIndex, u, v} + t */
@@ -241,14 +254,17 @@ int kkd_render_device(kkd_ctx *ctx, const kkd_render_params *params, void *dev_f
  * (any_hit: only prim!=0xFFFFFFFF / t<inf is meaningful). */
 int kkd_trace(kkd_ctx *ctx, const float *rays, uint64_t n, int any_hit, kkd_hit *out);
 
-/* Same with rays and hits resident in device memory (what the bench times). */
+/* Same queries (src/librender/skdtree.cpp:112-142, 207-226) with rays and hits resident in device memory, as
+ * the measurement protocol of src/utils/kdbench.cpp:210-242 times them. */
 int kkd_trace_device(kkd_ctx *ctx, const void *dev_rays, uint64_t n, int any_hit, void *dev_out, kkd_stats *stats);
 
 /* Counting variant of kkd_trace (host buffers): also reports visited nodes / tested triangles in
- * stats->nodes_visited / tris_tested, the measured N_nodes and N_tris of SURVEY 8d. */
+ * stats->nodes_visited / tris_tested, the measured N_nodes and N_tris of SURVEY 8d.  Plays the role of the
+ * reference's ray statistics counters (src/librender/skdtree.cpp:46-47,123,151,210). */
 int kkd_trace_counted(kkd_ctx *ctx, const float *rays, uint64_t n, int any_hit, kkd_hit *out, kkd_stats *stats);
 
-/* Sizes of the acceleration-structure records, for the algorithmic-bytes formula of SURVEY 8d. */
+/* Sizes of the acceleration-structure records, for the algorithmic-bytes formula of SURVEY 8d (the reference's
+ * records: 8-byte KDNode, 4-byte index, 48-byte TriAccel, src/librender/skdtree.cpp:77-79). */
 int kkd_accel_info(kkd_ctx *ctx, uint32_t *node_bytes, uint32_t *tri_bytes, uint64_t *n_nodes, uint64_t *n_leaf_tris);
 
 /* Asynchronous, thread-safe: replaces SamplingIntegrator::cancel (src/librender/integrator.cpp:90-93). */

@@ -168,6 +168,21 @@ int kkd_accel_info(kkd_ctx *ctx, uint32_t *node_bytes, uint32_t *tri_bytes, uint
     return KKD_OK;
 }
 
+static void fillCounterStats(kkd_stats *stats, const DeviceCounters &c, bool counted) {
+    stats->samples = c.samples;
+    stats->rays_closest = c.rays[KKD_RAYS_PRIMARY] + c.rays[KKD_RAYS_BSDF]; stats->rays_shadow = c.rays[KKD_RAYS_SHADOW];
+    double bytes = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        stats->class_rays[k] = c.rays[k]; stats->class_nodes[k] = c.nodes[k]; stats->class_tris[k] = c.tris[k];
+        stats->nodes_visited += c.nodes[k]; stats->tris_tested += c.tris[k];
+        /* B_ray of SURVEY 8d: ray read (none for primary rays, they are generated in registers) + result write
+         * (16-byte hit record, 4-byte occlusion word for shadow rays) + visited nodes + tested triangles */
+        const double io = k == KKD_RAYS_PRIMARY ? 16.0 : (k == KKD_RAYS_BSDF ? 48.0 : 36.0);
+        bytes += (double)c.rays[k] * io + (double)c.nodes[k] * sizeof(Node4) + (double)c.tris[k] * sizeof(LeafTri);
+    }
+    stats->algorithmic_bytes = counted ? bytes : 0.0;
+}
+
 /* ---- fixed ray sets ---- */
 static int traceImpl(kkd_ctx *ctx, const void *devRays, uint64_t n, int anyHit, void *devOut, bool count, kkd_stats *stats) {
     if (!ctx->haveScene) return fail(ctx, KKD_ERR_INVALID, "no scene uploaded");
@@ -180,7 +195,8 @@ static int traceImpl(kkd_ctx *ctx, const void *devRays, uint64_t n, int anyHit, 
     const uint64_t chunk = 1ull << 30;   /* keep grid sizes within 32 bits */
     for (uint64_t off = 0; off < n; off += chunk) {
         const uint64_t m = std::min(chunk, n - off);
-        launchTrace(ctx->stream, ctx->stackClass, ctx->ds, (const DRay *)devRays + off, m, anyHit != 0, count, 1, (DHit *)devOut + off, (DeviceCounters *)ctx->counters.p);
+        launchTrace(ctx->stream, ctx->stackClass, ctx->ds, (const DRay *)devRays + off, m, anyHit != 0, count, 1, (DHit *)devOut + off, (DeviceCounters *)ctx->counters.p,
+                    anyHit ? KKD_RAYS_SHADOW : KKD_RAYS_BSDF);
     }
     KKD_HIP(ctx, hipGetLastError());
     KKD_HIP(ctx, hipEventRecord(e1, ctx->stream));
@@ -192,11 +208,12 @@ static int traceImpl(kkd_ctx *ctx, const void *devRays, uint64_t n, int anyHit, 
     hipEventDestroy(e0); hipEventDestroy(e1);
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
-        stats->rays_closest = c.raysClosest; stats->rays_shadow = c.raysShadow;
+        fillCounterStats(stats, c, count);
+        /* the C-ABI trace entry points read 32-byte rays and write 16-byte hits for both ray kinds */
+        if (count) stats->algorithmic_bytes += 12.0 * (double)c.rays[KKD_RAYS_SHADOW];
         stats->seconds = stats->seconds_trace = ms * 1e-3;
-        stats->nodes_visited = c.nodes; stats->tris_tested = c.tris;
-        const double rays = (double)(c.raysClosest + c.raysShadow);
-        stats->algorithmic_bytes = rays * 48.0 + (count ? (double)c.nodes * sizeof(Node4) + (double)c.tris * sizeof(LeafTri) : 0.0);
+        const int stage = anyHit ? KKD_STAGE_SHADOW : KKD_STAGE_BSDF;
+        stats->stage_seconds[stage] = ms * 1e-3; stats->stage_launches[stage] = (n + chunk - 1) / chunk;
     }
     return KKD_OK;
 }
@@ -282,8 +299,10 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     bp.tileIndex = tileIndex; bp.tileCount = tileCount; bp.nTilesMine = nTilesMine; bp.W = W; bp.H = H;
 
     const uint64_t nBatches = (total + batch - 1) / batch;
-    const bool timeTrace = stats != nullptr && nBatches <= 4096;
-    const size_t nEvents = 2 + (timeTrace ? (size_t)nBatches * 2 * 3 : 0);
+    const bool count = (ctx->cfg.flags & KKD_FLAG_COUNT_TRAVERSAL) != 0;
+    /* one event between consecutive kernels of a batch: 6 per batch, on the stream the kernels run on */
+    const bool timeStages = stats != nullptr && nBatches <= 8192;
+    const size_t nEvents = 2 + (timeStages ? (size_t)nBatches * 6 : 0);
     while (ctx->events.size() < nEvents) { hipEvent_t ev; KKD_HIP(ctx, hipEventCreate(&ev)); ctx->events.push_back(ev); }
 
     hipStream_t st = ctx->stream;
@@ -291,23 +310,25 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     KKD_HIP(ctx, hipMemsetAsync(ctr, 0, sizeof(DeviceCounters), st));
     KKD_HIP(ctx, hipEventRecord(ctx->events[0], st));
     size_t ev = 2;
+    uint64_t launches[5] = { 0, 0, 0, 0, 0 };
     bool cancelled = false;
     for (uint64_t w0 = 0; w0 < total; w0 += batch) {
         if (ctx->cancel.load()) { cancelled = true; break; }
         bp.w0 = w0; bp.count = (uint32_t)std::min<uint64_t>(batch, total - w0);
-        if (timeTrace) hipEventRecord(ctx->events[ev++], st);
-        launchPrimary(st, ctx->stackClass, ctx->ds, bp, wb.hits, ctr);
-        if (timeTrace) hipEventRecord(ctx->events[ev++], st);
-        launchShade(st, ctx->ds, bp, wb);
-        if (timeTrace) hipEventRecord(ctx->events[ev++], st);
+        if (timeStages) hipEventRecord(ctx->events[ev++], st);
+        launchPrimary(st, ctx->stackClass, count, ctx->ds, bp, wb.hits, ctr); launches[KKD_STAGE_PRIMARY]++;
+        if (timeStages) hipEventRecord(ctx->events[ev++], st);
+        launchShade(st, ctx->ds, bp, wb); launches[KKD_STAGE_SHADE]++;
+        if (timeStages) hipEventRecord(ctx->events[ev++], st);
         /* all nB planes are contiguous when count == stride; otherwise trace plane by plane */
-        if (bp.count == bp.stride) launchTrace(st, ctx->stackClass, ctx->ds, wb.bsdfRays, (uint64_t)S * nB, false, false, 0, wb.bsdfHits, ctr);
-        else for (uint32_t b = 0; b < nB; ++b) launchTrace(st, ctx->stackClass, ctx->ds, wb.bsdfRays + (size_t)b * S, bp.count, false, false, 0, wb.bsdfHits + (size_t)b * S, ctr);
-        if (timeTrace) { hipEventRecord(ctx->events[ev++], st); hipEventRecord(ctx->events[ev++], st); }
-        if (bp.count == bp.stride) launchTrace(st, ctx->stackClass, ctx->ds, wb.shadowRays, (uint64_t)S * nL, true, false, 2, wb.occluded, ctr);
-        else for (uint32_t l = 0; l < nL; ++l) launchTrace(st, ctx->stackClass, ctx->ds, wb.shadowRays + (size_t)l * S, bp.count, true, false, 2, wb.occluded + (size_t)l * S, ctr);
-        if (timeTrace) hipEventRecord(ctx->events[ev++], st);
-        launchResolve(st, ctx->ds, bp, wb, film, ctr);
+        if (bp.count == bp.stride) { launchTrace(st, ctx->stackClass, ctx->ds, wb.bsdfRays, (uint64_t)S * nB, false, count, 0, wb.bsdfHits, ctr, KKD_RAYS_BSDF); launches[KKD_STAGE_BSDF]++; }
+        else for (uint32_t b = 0; b < nB; ++b) { launchTrace(st, ctx->stackClass, ctx->ds, wb.bsdfRays + (size_t)b * S, bp.count, false, count, 0, wb.bsdfHits + (size_t)b * S, ctr, KKD_RAYS_BSDF); launches[KKD_STAGE_BSDF]++; }
+        if (timeStages) hipEventRecord(ctx->events[ev++], st);
+        if (bp.count == bp.stride) { launchTrace(st, ctx->stackClass, ctx->ds, wb.shadowRays, (uint64_t)S * nL, true, count, 2, wb.occluded, ctr, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++; }
+        else for (uint32_t l = 0; l < nL; ++l) { launchTrace(st, ctx->stackClass, ctx->ds, wb.shadowRays + (size_t)l * S, bp.count, true, count, 2, wb.occluded + (size_t)l * S, ctr, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++; }
+        if (timeStages) hipEventRecord(ctx->events[ev++], st);
+        launchResolve(st, ctx->ds, bp, wb, film, ctr); launches[KKD_STAGE_RESOLVE]++;
+        if (timeStages) hipEventRecord(ctx->events[ev++], st);
     }
     KKD_HIP(ctx, hipGetLastError());
     KKD_HIP(ctx, hipEventRecord(ctx->events[1], st));
@@ -318,11 +339,12 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         std::memset(stats, 0, sizeof(*stats));
         float ms = 0.f;
         KKD_HIP(ctx, hipEventElapsedTime(&ms, ctx->events[0], ctx->events[1]));
-        stats->samples = c.samples; stats->rays_closest = c.raysClosest; stats->rays_shadow = c.raysShadow;
+        fillCounterStats(stats, c, count);
         stats->seconds = ms * 1e-3;
-        double traceMs = 0.0;
-        if (timeTrace) for (size_t k = 2; k + 1 < ev; k += 2) { float t = 0.f; if (hipEventElapsedTime(&t, ctx->events[k], ctx->events[k + 1]) == hipSuccess) traceMs += t; }
-        stats->seconds_trace = traceMs * 1e-3;
+        if (timeStages) for (size_t k = 2; k + 5 < ev; k += 6)
+            for (int sIdx = 0; sIdx < 5; ++sIdx) { float t = 0.f; if (hipEventElapsedTime(&t, ctx->events[k + sIdx], ctx->events[k + sIdx + 1]) == hipSuccess) stats->stage_seconds[sIdx] += t * 1e-3; }
+        for (int sIdx = 0; sIdx < 5; ++sIdx) stats->stage_launches[sIdx] = launches[sIdx];
+        stats->seconds_trace = stats->stage_seconds[KKD_STAGE_PRIMARY] + stats->stage_seconds[KKD_STAGE_BSDF] + stats->stage_seconds[KKD_STAGE_SHADOW];
     }
     if (cancelled) return fail(ctx, KKD_ERR_CANCELLED, "render cancelled");
     return KKD_OK;

@@ -5,7 +5,8 @@
 
 namespace kkd {
 
-struct DeviceCounters { unsigned long long samples, raysClosest, raysShadow, nodes, tris, pad[3]; };
+/* per ray class (KKD_RAYS_PRIMARY / _BSDF / _SHADOW) */
+struct DeviceCounters { unsigned long long samples, pad; unsigned long long rays[3], nodes[3], tris[3]; };
 
 /* One batch = work items [w0, w0 + count) of the render; see mapWorkItem() in kkd_kernels.hip. */
 struct BatchParams {
@@ -31,9 +32,10 @@ struct WaveBuffers {
 };
 
 /* stackClass: 0 = 32-entry LDS stack, 256-thread blocks; 1 = 96-entry stack, 64-thread blocks */
-void launchPrimary(hipStream_t st, int stackClass, const DScene &sc, const BatchParams &bp, DHit *hits, DeviceCounters *ctr);
+void launchPrimary(hipStream_t st, int stackClass, bool count, const DScene &sc, const BatchParams &bp, DHit *hits, DeviceCounters *ctr);
 /* outMode: 0 = DHit with LeafTri slot, 1 = DHit with global primitive id, 2 = uint32 occlusion flags (anyHit only) */
-void launchTrace(hipStream_t st, int stackClass, const DScene &sc, const DRay *rays, uint64_t n, bool anyHit, bool count, int outMode, void *out, DeviceCounters *ctr);
+/* rayClass: which DeviceCounters slot the launch accounts to */
+void launchTrace(hipStream_t st, int stackClass, const DScene &sc, const DRay *rays, uint64_t n, bool anyHit, bool count, int outMode, void *out, DeviceCounters *ctr, int rayClass);
 void launchShade(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb);
 void launchResolve(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb, float *film, DeviceCounters *ctr);
 

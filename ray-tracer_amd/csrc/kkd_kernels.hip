@@ -65,7 +65,12 @@ __device__ __forceinline__ void countRays(bool traced, unsigned long long *count
 }
 
 /* ---- K1+K2: primary rays ------------------------------------------------------------------------- */
-template <int STACK, int BLOCK>
+__device__ __forceinline__ void countTraversal(uint32_t nn, uint32_t nt, DeviceCounters *ctr, int cls) {
+    for (int m = 32; m > 0; m >>= 1) { nn += __shfl_xor(nn, m); nt += __shfl_xor(nt, m); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&ctr->nodes[cls], (unsigned long long)nn); atomicAdd(&ctr->tris[cls], (unsigned long long)nt); }
+}
+
+template <bool COUNT, int STACK, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) kPrimary(DScene sc, BatchParams bp, DHit *__restrict__ hits, DeviceCounters *ctr) {
     __shared__ uint32_t sstack[STACK * BLOCK];
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
@@ -74,16 +79,17 @@ __global__ void __launch_bounds__(BLOCK) kPrimary(DScene sc, BatchParams bp, DHi
     float sx, sy;
     if (s.active) ray = primaryRay(sc, bp, s, sx, sy);
     uint32_t nn = 0, nt = 0;
-    const DHit h = traverse<false, false, STACK, BLOCK>(sc.nodes, sc.tris, ray, sstack, nn, nt);
+    const DHit h = traverse<false, COUNT, STACK, BLOCK>(sc.nodes, sc.tris, ray, sstack, nn, nt);
     if (i < bp.count) hits[i] = h;
-    countRays(s.active, &ctr->raysClosest);
+    countRays(s.active, &ctr->rays[KKD_RAYS_PRIMARY]);
+    if (COUNT) countTraversal(nn, nt, ctr, KKD_RAYS_PRIMARY);
 }
 
 /* ---- generic ray-buffer traversal ------------------------------------------------------------------ */
 /* OUT: 0 = DHit with LeafTri slot (internal), 1 = DHit with global primitive id (C ABI), 2 = occlusion word */
 template <bool ANY, bool COUNT, int OUT, int STACK, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) kTrace(const Node4 *__restrict__ nodes, const LeafTri *__restrict__ tris,
-                                                const DRay *__restrict__ rays, uint64_t n, void *__restrict__ out, DeviceCounters *ctr) {
+                                                const DRay *__restrict__ rays, uint64_t n, void *__restrict__ out, DeviceCounters *ctr, int cls) {
     __shared__ uint32_t sstack[STACK * BLOCK];
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     DRay ray; ray.maxt = -1.f; ray.mint = 0.f; ray.ox = ray.oy = ray.oz = 0.f; ray.dx = ray.dy = 0.f; ray.dz = 1.f;
@@ -99,11 +105,8 @@ __global__ void __launch_bounds__(BLOCK) kTrace(const Node4 *__restrict__ nodes,
     }
     if (ctr) {
         const bool traced = i < n && ray.maxt > adaptiveMinT<ANY>(ray.mint, ray.ox, ray.oy, ray.oz);
-        countRays(traced, ANY ? &ctr->raysShadow : &ctr->raysClosest);
-        if (COUNT) {
-            for (int m = 32; m > 0; m >>= 1) { nn += __shfl_xor(nn, m); nt += __shfl_xor(nt, m); }
-            if ((threadIdx.x & 63) == 0) { atomicAdd(&ctr->nodes, (unsigned long long)nn); atomicAdd(&ctr->tris, (unsigned long long)nt); }
-        }
+        countRays(traced, &ctr->rays[cls]);
+        if (COUNT) countTraversal(nn, nt, ctr, cls);
     }
 }
 
@@ -289,25 +292,30 @@ __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveB
 /* ---- host launchers ---------------------------------------------------------------------------------- */
 static inline uint32_t blocksFor(uint64_t n, uint32_t block) { return (uint32_t)((n + block - 1) / block); }
 
-void launchPrimary(hipStream_t st, int stackClass, const DScene &sc, const BatchParams &bp, DHit *hits, DeviceCounters *ctr) {
-    if (stackClass == 0) hipLaunchKernelGGL((kPrimary<32, 256>), dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, hits, ctr);
-    else hipLaunchKernelGGL((kPrimary<96, 64>), dim3(blocksFor(bp.count, 64)), dim3(64), 0, st, sc, bp, hits, ctr);
+void launchPrimary(hipStream_t st, int stackClass, bool count, const DScene &sc, const BatchParams &bp, DHit *hits, DeviceCounters *ctr) {
+    if (stackClass == 0) {
+        if (count) hipLaunchKernelGGL((kPrimary<true, 32, 256>), dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, hits, ctr);
+        else hipLaunchKernelGGL((kPrimary<false, 32, 256>), dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, hits, ctr);
+    } else {
+        if (count) hipLaunchKernelGGL((kPrimary<true, 96, 64>), dim3(blocksFor(bp.count, 64)), dim3(64), 0, st, sc, bp, hits, ctr);
+        else hipLaunchKernelGGL((kPrimary<false, 96, 64>), dim3(blocksFor(bp.count, 64)), dim3(64), 0, st, sc, bp, hits, ctr);
+    }
 }
 
 template <bool ANY, bool COUNT, int OUT>
-static void launchTraceT(hipStream_t st, int stackClass, const DScene &sc, const DRay *rays, uint64_t n, void *out, DeviceCounters *ctr) {
-    if (stackClass == 0) hipLaunchKernelGGL((kTrace<ANY, COUNT, OUT, 32, 256>), dim3(blocksFor(n, 256)), dim3(256), 0, st, sc.nodes, sc.tris, rays, n, out, ctr);
-    else hipLaunchKernelGGL((kTrace<ANY, COUNT, OUT, 96, 64>), dim3(blocksFor(n, 64)), dim3(64), 0, st, sc.nodes, sc.tris, rays, n, out, ctr);
+static void launchTraceT(hipStream_t st, int stackClass, const DScene &sc, const DRay *rays, uint64_t n, void *out, DeviceCounters *ctr, int cls) {
+    if (stackClass == 0) hipLaunchKernelGGL((kTrace<ANY, COUNT, OUT, 32, 256>), dim3(blocksFor(n, 256)), dim3(256), 0, st, sc.nodes, sc.tris, rays, n, out, ctr, cls);
+    else hipLaunchKernelGGL((kTrace<ANY, COUNT, OUT, 96, 64>), dim3(blocksFor(n, 64)), dim3(64), 0, st, sc.nodes, sc.tris, rays, n, out, ctr, cls);
 }
 
-void launchTrace(hipStream_t st, int stackClass, const DScene &sc, const DRay *rays, uint64_t n, bool anyHit, bool count, int outMode, void *out, DeviceCounters *ctr) {
+void launchTrace(hipStream_t st, int stackClass, const DScene &sc, const DRay *rays, uint64_t n, bool anyHit, bool count, int outMode, void *out, DeviceCounters *ctr, int cls) {
     if (n == 0) return;
     if (anyHit) {
-        if (outMode == 2) { if (count) launchTraceT<true, true, 2>(st, stackClass, sc, rays, n, out, ctr); else launchTraceT<true, false, 2>(st, stackClass, sc, rays, n, out, ctr); }
-        else { if (count) launchTraceT<true, true, 1>(st, stackClass, sc, rays, n, out, ctr); else launchTraceT<true, false, 1>(st, stackClass, sc, rays, n, out, ctr); }
+        if (outMode == 2) { if (count) launchTraceT<true, true, 2>(st, stackClass, sc, rays, n, out, ctr, cls); else launchTraceT<true, false, 2>(st, stackClass, sc, rays, n, out, ctr, cls); }
+        else { if (count) launchTraceT<true, true, 1>(st, stackClass, sc, rays, n, out, ctr, cls); else launchTraceT<true, false, 1>(st, stackClass, sc, rays, n, out, ctr, cls); }
     } else {
-        if (outMode == 0) { if (count) launchTraceT<false, true, 0>(st, stackClass, sc, rays, n, out, ctr); else launchTraceT<false, false, 0>(st, stackClass, sc, rays, n, out, ctr); }
-        else { if (count) launchTraceT<false, true, 1>(st, stackClass, sc, rays, n, out, ctr); else launchTraceT<false, false, 1>(st, stackClass, sc, rays, n, out, ctr); }
+        if (outMode == 0) { if (count) launchTraceT<false, true, 0>(st, stackClass, sc, rays, n, out, ctr, cls); else launchTraceT<false, false, 0>(st, stackClass, sc, rays, n, out, ctr, cls); }
+        else { if (count) launchTraceT<false, true, 1>(st, stackClass, sc, rays, n, out, ctr, cls); else launchTraceT<false, false, 1>(st, stackClass, sc, rays, n, out, ctr, cls); }
     }
 }
 

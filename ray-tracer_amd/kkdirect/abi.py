@@ -14,7 +14,9 @@ DISTR_BECKMANN, DISTR_GGX, DISTR_PHONG = range(3)
 EMITTER_AREA, EMITTER_POINT, EMITTER_ENVMAP = range(3)
 RFILTER_GAUSSIAN, RFILTER_BOX, RFILTER_TENT, RFILTER_MITCHELL, RFILTER_CATMULLROM, RFILTER_LANCZOS = range(6)
 SHAPE_HAS_NORMALS, SHAPE_HAS_TEXCOORDS = 1, 2
-SPLIT_TILE, SPLIT_SAMPLE = 0, 1
+FLAG_COUNT_TRAVERSAL = 1
+RAYS_PRIMARY, RAYS_BSDF, RAYS_SHADOW = 0, 1, 2
+STAGE_NAMES = ("primary", "shade", "bsdf", "shadow", "resolve")
 
 f32, u32, i32, u64 = C.c_float, C.c_uint32, C.c_int32, C.c_uint64
 pf32, pu32 = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
@@ -59,7 +61,7 @@ class SceneDesc(C.Structure):
 
 
 class Config(C.Structure):
-    _fields_ = [("device", i32), ("split_mode", i32), ("seed", u64), ("max_samples_in_flight", u64)]
+    _fields_ = [("device", i32), ("flags", u32), ("seed", u64), ("max_samples_in_flight", u64)]
 
 
 class RenderParams(C.Structure):
@@ -70,7 +72,9 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("samples", u64), ("rays_closest", u64), ("rays_shadow", u64), ("seconds", C.c_double),
                 ("seconds_trace", C.c_double), ("algorithmic_bytes", C.c_double),
-                ("nodes_visited", u64), ("tris_tested", u64)]
+                ("nodes_visited", u64), ("tris_tested", u64),
+                ("class_rays", u64 * 3), ("class_nodes", u64 * 3), ("class_tris", u64 * 3),
+                ("stage_seconds", C.c_double * 5), ("stage_launches", u64 * 5)]
 
 
 class Hit(C.Structure):

@@ -1,0 +1,376 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI of libkkdirect.so, against
+the oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star):
+  * hit primitive ids on fixed ray sets: equal to the oracle's ShapeKDTree restatement except documented
+    edge/vertex/equal-distance ties, which must stay <= 1e-5 of the rays on the config-shaped scenes;
+  * images: relMSE <= 1e-3 against a converged reference at matched spp; with the same sample stream the GPU and the
+    oracle evaluate the same samples, so the same-seed comparison is far tighter and is asserted as well.
+"""
+import os
+import threading
+import time
+import numpy as np
+import pytest
+import kkoracle
+from kkdirect import Scene, abi, scenes, look_at, compute_vertex_normals
+import helpers
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MISS = 0xFFFFFFFF
+
+
+def _ctx(gpu, scene, **kw):
+    return gpu.Context(device=0, **kw).upload(scene)
+
+
+def _check_ids(scene, rays, a, b, max_frac):
+    n_bad = int((a["prim"] != b["prim"]).sum())
+    unexplained = helpers.classify_mismatches(scene, rays, a, b)
+    assert unexplained == 0, "%d mismatches that are not edge/vertex/equal-t ties" % unexplained
+    assert n_bad <= max(1, int(max_frac * len(rays))), "%d of %d rays differ" % (n_bad, len(rays))
+    same = a["prim"] == b["prim"]
+    hit = same & (a["prim"] != MISS)
+    np.testing.assert_allclose(b["t"][hit], a["t"][hit], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(b["u"][hit], a["u"][hit], atol=2e-4)
+    np.testing.assert_allclose(b["v"][hit], a["v"][hit], atol=2e-4)
+    return n_bad
+
+
+def _secondary_rays(o, scene, n, seed):
+    """incoherent rays leaving surfaces with mint = Epsilon (the adaptive-epsilon case of skdtree.cpp:126-132)"""
+    rng = np.random.RandomState(seed)
+    sp = rng.rand(n, 2).astype(np.float32) * [o.width, o.height]
+    cam = o.camera_rays(sp)
+    h = o.trace(cam)
+    ok = h["prim"] != MISS
+    p = cam[ok, 0:3] + cam[ok, 4:7] * h["t"][ok, None]
+    d = rng.normal(size=(len(p), 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros((len(p), 8), np.float32)
+    rays[:, 0:3] = p; rays[:, 3] = 1e-4; rays[:, 4:7] = d; rays[:, 7] = np.inf
+    return cam, rays
+
+
+# ------------------------------------------------------------------------------------------- hit ids
+def test_hit_ids_cornell_camera_and_chords(gpu):
+    sc = scenes.cornell_box(512, 512)
+    o = kkoracle.Oracle(sc)
+    with _ctx(gpu, sc) as ctx:
+        rng = np.random.RandomState(0)
+        cam = o.camera_rays(rng.rand(1_000_000, 2).astype(np.float32) * 512)
+        _check_ids(sc, cam, o.trace(cam), ctx.trace(cam), 1e-5)
+        chords = helpers.chord_rays(500_000, (278, 274, 280), 500.0, seed=1)
+        _check_ids(sc, chords, o.trace(chords), ctx.trace(chords), 1e-5)
+        sa, sb = o.trace(chords, any_hit=True), ctx.trace(chords, any_hit=True)
+        assert ((sa["prim"] != MISS) != (sb["prim"] != MISS)).sum() <= 5
+
+
+@pytest.mark.parametrize("normals", [False, True])
+def test_hit_ids_triangle_soup(gpu, normals):
+    sc = helpers.triangle_soup(6000, seed=3, normals=normals)
+    o = kkoracle.Oracle(sc)
+    with _ctx(gpu, sc) as ctx:
+        rays = helpers.chord_rays(300_000, (0, 0, 0), 9.0, seed=2)
+        # intersecting random triangles create many equal-distance crossings; ties are classified, not bounded at 1e-5
+        _check_ids(sc, rays, o.trace(rays), ctx.trace(rays), 1e-4)
+        brute = o.trace(rays[:20000], brute=True)
+        _check_ids(sc, rays[:20000], brute, ctx.trace(rays[:20000]), 1e-4)
+
+
+def test_hit_ids_sponza_class_primary_and_secondary(gpu):
+    sc = scenes.sponza_class(256, 144, target_tris=60_000)
+    o = kkoracle.Oracle(sc)
+    with _ctx(gpu, sc) as ctx:
+        cam, sec = _secondary_rays(o, sc, 300_000, seed=5)
+        _check_ids(sc, cam, o.trace(cam), ctx.trace(cam), 1e-5)
+        _check_ids(sc, sec, o.trace(sec), ctx.trace(sec), 2e-5)
+        sa, sb = o.trace(sec, any_hit=True), ctx.trace(sec, any_hit=True)
+        assert ((sa["prim"] != MISS) != (sb["prim"] != MISS)).mean() <= 2e-5
+        hits, st = ctx.trace(cam, counted=True)
+        assert st.class_rays[abi.RAYS_BSDF] == len(cam) and st.nodes_visited > len(cam) and st.tris_tested > 0
+        assert st.algorithmic_bytes > 48 * len(cam)
+        info = ctx.accel_info()
+        assert info["node_bytes"] == 128 and info["tri_bytes"] == 48 and info["n_leaf_tris"] == sc._nt
+
+
+def test_trace_edge_cases(gpu):
+    """empty ray set, empty interval, axis-aligned directions, rays through shared edges and vertices (watertight:
+    no ray may slip between two triangles of a closed grid), degenerate triangles in the scene."""
+    n = 33
+    xs = np.linspace(-1, 1, n, dtype=np.float32)
+    X, Z = np.meshgrid(xs, xs, indexing="ij")
+    pos = np.stack([X, 0.1 * np.sin(3 * X) * np.cos(2 * Z), Z], -1).reshape(-1, 3).astype(np.float32)
+    idx = scenes._grid(n - 1, n - 1)
+    sc = Scene(); m = sc.diffuse()
+    sc.add_mesh(pos, idx, m)
+    sc.add_mesh([[5, 5, 5], [5, 5, 5], [6, 6, 6], [2, 2, 2], [3, 3, 3], [4, 4, 4]], [[0, 1, 2], [3, 4, 5]], m)   # zero-area triangles
+    sc.set_sensor(np.eye(4), 45, 8, 8)
+    o = kkoracle.Oracle(sc)
+    with _ctx(gpu, sc) as ctx:
+        assert len(ctx.trace(np.zeros((0, 8), np.float32))) == 0
+        # straight down through every interior vertex and edge midpoint
+        inner = pos.reshape(n, n, 3)[1:-1, 1:-1].reshape(-1, 3)
+        mids = 0.5 * (pos.reshape(n, n, 3)[1:-1, 1:-1] + pos.reshape(n, n, 3)[2:, 1:-1]).reshape(-1, 3)
+        targets = np.concatenate([inner, mids])
+        rays = np.zeros((len(targets), 8), np.float32)
+        rays[:, 0:3] = targets + [0, 2, 0]; rays[:, 4:7] = [0, -1, 0]; rays[:, 7] = np.inf
+        g = ctx.trace(rays)
+        assert (g["prim"] != MISS).all(), "a ray leaked through a shared edge/vertex"
+        np.testing.assert_allclose(g["t"], 2.0, atol=1e-4)
+        # oblique rays aimed exactly at vertices
+        rays2 = rays.copy(); rays2[:, 0:3] = targets + [0.7, 1.9, -0.4]
+        d = targets - rays2[:, 0:3]; rays2[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
+        g2 = ctx.trace(rays2)
+        assert (g2["prim"] != MISS).mean() > 0.999
+        # empty and inverted intervals never hit
+        r3 = rays.copy(); r3[:, 3] = 5.0; r3[:, 7] = 1.0
+        assert (ctx.trace(r3)["prim"] == MISS).all()
+        r4 = rays.copy(); r4[:, 7] = 1.5
+        assert (ctx.trace(r4)["prim"] == MISS).all() and (ctx.trace(r4, any_hit=True)["prim"] == MISS).all()
+        # the degenerate triangles are never reported
+        r5 = np.array([[5.5, 9, 5.5, 0, 0, -1, 0, np.inf], [0, 1, 0, 0, 0, -1, 0, np.inf]], np.float32)
+        h5 = ctx.trace(r5)
+        assert h5["prim"][0] == MISS and h5["prim"][1] != MISS
+        np.testing.assert_array_equal(h5["prim"], o.trace(r5)["prim"])
+
+
+def test_adaptive_epsilon_rule_on_gpu(gpu):
+    sc = Scene(); m = sc.diffuse()
+    sc.add_mesh([[99, -1, 0], [101, -1, 0], [100, 1, 0]], [[0, 1, 2]], m)
+    sc.add_mesh([[99, -1, 5], [101, -1, 5], [100, 1, 5]], [[0, 1, 2]], m)
+    sc.set_sensor(np.eye(4), 45, 8, 8)
+    o = kkoracle.Oracle(sc)
+    with _ctx(gpu, sc) as ctx:
+        r = np.array([[100, 0, -1e-3, 1e-4, 0, 0, 1, np.inf], [100, 0, -1e-3, 2e-4, 0, 0, 1, np.inf]], np.float32)
+        g = ctx.trace(r)
+        assert list(g["prim"]) == [1, 0] == list(o.trace(r)["prim"])
+        # shadow rays: epsilon scales with |o| without the inner clamp (skdtree.cpp:213-216)
+        r0 = np.array([[0, 0, 0, 1e-4, 0, 0, 1, np.inf]], np.float32)
+        assert (ctx.trace(r0, any_hit=True)["prim"] == MISS).all() == (o.trace(r0, any_hit=True)["prim"] == MISS).all()
+
+
+# ------------------------------------------------------------------------------------------- images
+def _same_seed(gpu, sc, spp, tol=1e-5, **kw):
+    o = kkoracle.Oracle(sc)
+    ref, so = o.render(spp, seed=1, **kw)
+    with _ctx(gpu, sc, seed=1) as ctx:
+        film, sg = ctx.render(spp, **kw)
+    a, b = helpers.develop(film), helpers.develop(ref)
+    r = helpers.rel_mse(a, b)
+    assert np.isfinite(film).all() and (film >= 0).all()
+    assert sg.samples == so.samples
+    np.testing.assert_allclose(film[..., 4].sum(), ref[..., 4].sum(), rtol=1e-4)
+    assert r < tol, r
+    return film, ref, sg, so
+
+
+def test_cornell_same_sample_stream(gpu):
+    sc = scenes.cornell_box(128, 128)
+    film, ref, sg, so = _same_seed(gpu, sc, 64)
+    assert sg.rays_closest == so.rays_closest          # "Normal rays traced" identical
+    assert 0 < sg.rays_shadow <= so.rays_shadow          # shadow rays with zero contribution are not launched
+    assert sg.stage_launches[abi.STAGE_NAMES.index("primary")] >= 1 and sg.seconds > 0
+    assert abs(sum(sg.stage_seconds) - sg.seconds) < 0.5 * sg.seconds + 1e-3
+
+
+def test_cornell_converged_reference(gpu):
+    """relMSE <= 1e-3 against the committed converged oracle image (tests/golden/make_golden.py) at matched spp,
+    with an independent sample stream."""
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "cornell_64x64_4096spp_oracle.npy"))
+    sc = scenes.cornell_box(64, 64)
+    with _ctx(gpu, sc, seed=99) as ctx:
+        film, st = ctx.render(4096)
+    r = helpers.rel_mse(helpers.develop(film), ref)
+    assert r <= 1e-3, r
+
+
+def _material_scene(w=96, h=64, env=True, area=True, point=True):
+    """every BSDF / emitter type on the path in one frame"""
+    rng = np.random.RandomState(8)
+    sc = Scene()
+    mats = [sc.twosided(sc.diffuse((0.6, 0.5, 0.4))),
+            sc.roughconductor((0.143, 0.375, 1.442), (3.983, 2.386, 1.603), alpha=0.2, distribution=abi.DISTR_GGX),
+            sc.roughconductor((0.2, 0.92, 1.1), (3.9, 2.45, 2.14), alpha=0.25, alpha_v=0.08),
+            sc.roughconductor((0.2, 0.92, 1.1), (3.9, 2.45, 2.14), alpha=0.15, sample_visible=False, distribution=abi.DISTR_PHONG),
+            sc.roughplastic((0.2, 0.4, 0.6), alpha=0.1),
+            sc.roughplastic((0.5, 0.3, 0.2), alpha=0.3, distribution=abi.DISTR_GGX, nonlinear=True),
+            sc.dielectric(1.5046),
+            sc.twosided(sc.roughplastic((0.4, 0.4, 0.1), alpha=0.2), sc.diffuse((0.1, 0.5, 0.2)))]
+    sc.add_mesh([[-6, 0, -6], [-6, 0, 6], [6, 0, 6], [6, 0, -6]], [[0, 1, 2], [0, 2, 3]], mats[0])
+    for k, m in enumerate(mats[1:]):
+        p, i = scenes.cube_sphere(10, 0.55, 0.05, seed=k, center=(-3.6 + 1.2 * k, 0.6, 0.4 * (k % 2)))
+        uv = np.stack([np.arctan2(p[:, 0] - (-3.6 + 1.2 * k), p[:, 2]) / 6.28 + 0.5, p[:, 1]], 1).astype(np.float32)
+        sc.add_mesh(p, i, m, normals=compute_vertex_normals(p, i), texcoords=uv if k in (1, 4) else None)
+    if area:
+        sc.add_mesh([[-1, 3, -1], [-1, 3, 1], [1, 3, 1], [1, 3, -1]], [[0, 2, 1], [0, 3, 2]], sc.diffuse((0, 0, 0)), radiance=(12, 11, 9))
+    if point:
+        sc.add_point_light((3, 2, -2), (6, 7, 9))
+    if env:
+        tex = (rng.rand(16, 32, 3) ** 3).astype(np.float32); tex[4, 20] = (60, 50, 40)
+        sc.set_envmap(tex, scale=0.7)
+    sc.set_sensor(look_at((0, 2.2, -6.5), (0, 0.5, 0), (0, 1, 0)), 45, w, h, near=0.1, far=100)
+    return sc
+
+
+def test_all_materials_and_emitters_same_sample_stream(gpu):
+    _same_seed(gpu, _material_scene(), 32, tol=2e-4)
+
+
+def test_per_sample_radiance_parity(gpu):
+    """box filter, 1 spp: every film pixel is the radiance of one camera sample -> compare sample by sample"""
+    sc = _material_scene(128, 96)
+    sc.sensor.rfilter_type = abi.RFILTER_BOX; sc.sensor.rfilter_radius = 0.5
+    o = kkoracle.Oracle(sc)
+    ref, _ = o.render(1, seed=4)
+    with _ctx(gpu, sc, seed=4) as ctx:
+        film, _ = ctx.render(1)
+    np.testing.assert_array_equal(film[..., 4], ref[..., 4])
+    a, b = film[..., :3], ref[..., :3]
+    bad = (np.abs(a - b) > 1e-3 * (np.abs(b) + 1e-2)).any(-1)
+    # differing samples sit on discontinuities (a hit flipping across an edge, a branch decided by the last bit)
+    assert bad.mean() < 5e-3, bad.mean()
+
+
+@pytest.mark.parametrize("kw", [dict(bsdf_samples=3, light_samples=2), dict(bsdf_samples=1, light_samples=4), dict(hide_emitters=True),
+                                dict(block_size=24), dict(block_size=8)])
+def test_integrator_parameters(gpu, kw):
+    """bsdfSamples / lightSamples / hideEmitters of src/integrators/kk/direct.cpp:17-21; -b blockSize"""
+    _same_seed(gpu, _material_scene(64, 48), 16, tol=2e-4, **kw)
+
+
+@pytest.mark.parametrize("spp", [1, 3, 5, 100])
+def test_sample_counts_that_do_not_fill_a_wave(gpu, spp):
+    film, ref, sg, so = _same_seed(gpu, scenes.cornell_box(50, 38), spp, tol=1e-4)
+    assert sg.samples == 50 * 38 * spp
+
+
+@pytest.mark.parametrize("rfilter", [abi.RFILTER_BOX, abi.RFILTER_TENT, abi.RFILTER_MITCHELL, abi.RFILTER_CATMULLROM, abi.RFILTER_LANCZOS])
+def test_reconstruction_filters(gpu, rfilter):
+    """negative lobes (mitchell, catmullrom, lanczos) make film values signed; only the samples are required >= 0"""
+    sc = scenes.cornell_box(48, 48, rfilter=rfilter)
+    o = kkoracle.Oracle(sc)
+    ref, _ = o.render(16, seed=1)
+    with _ctx(gpu, sc, seed=1) as ctx:
+        film, _ = ctx.render(16)
+    np.testing.assert_allclose(film, ref, rtol=2e-3, atol=2e-3)
+
+
+def test_alpha_channel_and_crop_window(gpu):
+    sc = _material_scene(96, 64, env=False)
+    sc.sensor.film_has_alpha = 1
+    sc.sensor.crop_offset_x, sc.sensor.crop_offset_y, sc.sensor.crop_width, sc.sensor.crop_height = 20, 10, 50, 30
+    film, ref, _, _ = _same_seed(gpu, sc, 16, tol=2e-4)
+    alpha = film[..., 3] / np.maximum(film[..., 4], 1e-9)
+    assert alpha.min() < 0.05 and alpha.max() > 0.95          # sky pixels are transparent, geometry opaque
+    np.testing.assert_allclose(film[..., 3], ref[..., 3], rtol=1e-3, atol=1e-3)
+
+
+def test_tile_sharding_and_sample_split_sum_to_the_full_film(gpu):
+    """N ranks render disjoint tiles (with borders) or disjoint sample ranges; the sum-reduce of their films
+    is the film of the whole job, independent of N."""
+    sc = _material_scene(80, 56)
+    with _ctx(gpu, sc, seed=2) as ctx:
+        full, st = ctx.render(8)
+        for n in (2, 3):
+            parts = [ctx.render(8, tile_index=k, tile_count=n, block_size=16) for k in range(n)]
+            assert sum(p[1].samples for p in parts) == st.samples
+            np.testing.assert_allclose(sum(p[0] for p in parts), full, rtol=1e-4, atol=1e-5)
+        halves = [ctx.render(4, sample_first=4 * k)[0] for k in range(2)]
+        np.testing.assert_allclose(sum(halves), full, rtol=1e-4, atol=1e-5)
+        # a rank without tiles renders nothing
+        empty, se = ctx.render(8, tile_index=200, tile_count=201, block_size=32)
+        assert se.samples == 0 and not empty.any()
+
+
+def test_many_lights_emitter_cdf(gpu):
+    """C3 shape: hundreds of single-triangle area emitters -> Scene::m_emitterPDF binary search; and one emissive mesh
+    -> TriMesh area CDF"""
+    for single in (False, True):
+        sc = scenes.many_lights(96, 54, n_lights=400, interior_tris=8000, single_mesh=single)
+        _same_seed(gpu, sc, 16, tol=5e-4)
+
+
+def test_envmap_scanned_mesh_config_shape(gpu):
+    """C4 shape at reduced size: displaced mesh (roughconductor GGX) + dielectric + ground under an HDR envmap"""
+    sc = scenes.scanned_mesh(96, 54, n=48, env_size=(256, 128))
+    _same_seed(gpu, sc, 16, tol=1e-3)
+
+
+def test_device_film_entry_point(gpu):
+    import torch
+    sc = scenes.cornell_box(64, 64)
+    with _ctx(gpu, sc, seed=3) as ctx:
+        host, _ = ctx.render(8)
+        t = torch.full((64 * 64 * 5,), 7.0, dtype=torch.float32, device="cuda")
+        st = ctx.render_device(t.data_ptr(), 8)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(t.cpu().numpy().reshape(64, 64, 5), host, rtol=1e-4, atol=1e-5)
+        assert st.samples == 64 * 64 * 8
+        rays = torch.from_numpy(kkoracle.Oracle(sc).camera_rays(np.random.RandomState(0).rand(4096, 2) * 64)).cuda()
+        out = torch.zeros(4096 * 4, dtype=torch.float32, device="cuda")
+        st = ctx.trace_device(rays.data_ptr(), 4096, out.data_ptr())
+        torch.cuda.synchronize()
+        prim = out.view(torch.int32).reshape(-1, 4)[:, 3].cpu().numpy().astype(np.uint32)
+        np.testing.assert_array_equal(prim, ctx.trace(rays.cpu().numpy())["prim"])
+
+
+# ------------------------------------------------------------------------------------------- errors, cancel
+def test_error_behaviour(gpu):
+    sc = scenes.cornell_box(32, 32)
+    with _ctx(gpu, sc) as ctx:
+        for kw, code in ((dict(spp=0), abi.KKD_ERR_INVALID), (dict(spp=4, bsdf_samples=0), abi.KKD_ERR_UNSUPPORTED),
+                         (dict(spp=4, light_samples=0), abi.KKD_ERR_UNSUPPORTED), (dict(spp=4, block_size=1), abi.KKD_ERR_INVALID),
+                         (dict(spp=4, tile_index=3, tile_count=2), abi.KKD_ERR_INVALID)):
+            with pytest.raises(gpu.KKDError) as e:
+                ctx.render(**kw)
+            assert e.value.code == code and len(str(e.value)) > 20
+        film, _ = ctx.render(4)      # the context stays usable after an error
+        assert film[..., 4].sum() > 0
+    bad = scenes.cornell_box(32, 32)
+    bad._idx[0][0, 0] = 10_000
+    with pytest.raises(gpu.KKDError) as e:
+        gpu.Context().upload(bad)
+    assert e.value.code == abi.KKD_ERR_INVALID and "index" in str(e.value)
+    with pytest.raises(gpu.KKDError):
+        gpu.Context().render(4)      # no scene uploaded
+
+
+def test_cancel(gpu):
+    """SamplingIntegrator::cancel (src/librender/integrator.cpp:90-93): asynchronous, the render returns early"""
+    sc = scenes.sponza_class(512, 288, target_tris=20_000)
+    with _ctx(gpu, sc, max_samples_in_flight=1 << 16) as ctx:
+        result = {}
+        def run():
+            try:
+                ctx.render(4096)
+                result["rc"] = 0
+            except gpu.KKDError as e:
+                result["rc"] = e.code
+        th = threading.Thread(target=run); th.start()
+        time.sleep(0.05)
+        ctx.request_cancel()
+        th.join(60)
+        assert not th.is_alive() and result["rc"] == abi.KKD_ERR_CANCELLED
+        film, st = ctx.render(1)     # and the context renders again afterwards
+        assert st.samples == 512 * 288
+
+
+# ------------------------------------------------------------------------------------------- full-size properties
+def test_full_size_c2_properties(gpu):
+    """BASELINE.json config 2 at its full size (1920x1080, 256 spp, ~260k triangles): size-independent properties --
+    exact sample count, film weight = number of samples (normalised filter, minus what leaves the frame), linearity in
+    the sample range, finite non-negative film."""
+    sc = scenes.sponza_class(1920, 1080)
+    with _ctx(gpu, sc, seed=1) as ctx:
+        film, st = ctx.render(256)
+        n = 1920 * 1080 * 256
+        assert st.samples == n and st.class_rays[abi.RAYS_PRIMARY] == n
+        assert st.class_rays[abi.RAYS_BSDF] <= n and st.class_rays[abi.RAYS_SHADOW] <= n
+        assert np.isfinite(film).all() and film.min() >= 0
+        assert abs(film[..., 4].sum() / n - 1) < 0.01
+        interior = film[4:-4, 4:-4, 4]
+        assert abs(interior.mean() - 256) < 1.0
+        a, _ = ctx.render(128, sample_first=0); b, _ = ctx.render(128, sample_first=128)
+        np.testing.assert_allclose(a + b, film, rtol=2e-3, atol=2e-3)
+        # image-level agreement with the oracle on a crop at low spp happens in the config-shaped tests above

@@ -1,0 +1,112 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every symbol the header declares,
+the ctypes mirror matches the header, the scene builder and the DirectIntegrator mirror behave like the reference's
+plugin interface.  No compute calls (there is no GPU here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import numpy as np
+import pytest
+import kkdirect
+from kkdirect import abi, scenes, Scene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "kkdirect.h")
+
+
+def test_library_exports_every_declared_symbol():
+    src = open(HEADER).read()
+    declared = set(re.findall(r"\b(kkd_[a-z_]+)\s*\(", src))
+    assert declared == set(abi.ENTRY_POINTS), declared ^ set(abi.ENTRY_POINTS)
+    lib = kkdirect.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_struct_layouts_match_the_c_compiler(tmp_path):
+    """sizeof/offsetof as gcc sees include/kkdirect.h == the ctypes mirror"""
+    structs = {"kkd_shape": abi.Shape, "kkd_material": abi.Material, "kkd_emitter": abi.Emitter, "kkd_envmap": abi.EnvMap,
+               "kkd_sensor": abi.Sensor, "kkd_scene_desc": abi.SceneDesc, "kkd_config": abi.Config,
+               "kkd_render_params": abi.RenderParams, "kkd_stats": abi.Stats, "kkd_hit": abi.Hit}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % HEADER, "int main(void){"]
+    for cname, cls in structs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, f[0], cname, f[0]))
+    lines.append("return 0;}")
+    c = tmp_path / "layout.c"; c.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-o", str(exe), str(c)])
+    out = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    for cname, cls in structs.items():
+        assert int(out[cname]) == C.sizeof(cls), cname
+        for f in cls._fields_:
+            assert int(out["%s.%s" % (cname, f[0])]) == getattr(cls, f[0]).offset, (cname, f[0])
+
+
+def test_header_cites_the_reference_for_every_entry_point():
+    src = open(HEADER).read()
+    for name in abi.ENTRY_POINTS:
+        i = re.search(r"^[\w][\w \*]*\b%s\(" % name, src, re.M).start()
+        comment = src[src.rfind("/*", 0, i):i]
+        assert re.search(r"\.(cpp|h):\d+", comment) or "counterpart" in comment, name
+
+
+def test_no_gpu_means_loud_failure():
+    """The product has no CPU fallback: on a machine without a HIP device creating a context fails with a message."""
+    if kkdirect.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(kkdirect.KKDError) as e:
+        kkdirect.Context()
+    assert "no HIP device" in str(e.value)
+
+
+def test_product_never_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use oracle/."""
+    for base, _, files in os.walk(os.path.join(ROOT, "ray-tracer_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".cpp", ".hip", "Makefile")):
+                text = open(os.path.join(base, f), errors="ignore").read()
+                assert "kkoracle" not in text and "oracle/" not in text and "ora_" not in text, os.path.join(base, f)
+    out = subprocess.run(["ldd", kkdirect.LIB_PATH], capture_output=True, text=True).stdout
+    assert "kkoracle" not in out
+
+
+def test_direct_integrator_mirrors_plugin_parameters():
+    """reference src/integrators/kk/direct.cpp:17-36: bsdfSamples, lightSamples (size_t, default 1), hideEmitters
+    (bool, default false); serialised in that order."""
+    it = kkdirect.DirectIntegrator()
+    assert (it.bsdfSamples, it.lightSamples, it.hideEmitters) == (1, 1, False)
+    it = kkdirect.DirectIntegrator({"bsdfSamples": 4, "lightSamples": 2, "hideEmitters": True})
+    back = kkdirect.DirectIntegrator.unserialize(it.serialize())
+    assert (back.bsdfSamples, back.lightSamples, back.hideEmitters) == (4, 2, True)
+    assert kkdirect.DirectIntegrator.PLUGIN_NAME == "kkIntegrator"
+    with pytest.raises(ValueError):
+        kkdirect.DirectIntegrator({"shadingSamples": 3})   # a property of the stock 'direct' plugin, not of kk
+
+
+def test_scene_builder_flattening():
+    sc = scenes.cornell_box(32, 32)
+    d = sc.desc()
+    assert d.n_tris == 32 and d.n_shapes == 8 and d.n_emitters == 1
+    firsts = [d.shapes[i].first_prim for i in range(d.n_shapes)]
+    counts = [d.shapes[i].n_prims for i in range(d.n_shapes)]
+    assert firsts == list(np.cumsum([0] + counts[:-1]))           # global prim id = first_prim + primIndex
+    light = [i for i in range(d.n_shapes) if d.shapes[i].emitter_id >= 0]
+    assert len(light) == 1 and d.emitters[0].shape_id == light[0]
+    idx = np.ctypeslib.as_array(d.indices, shape=(d.n_tris * 3,))
+    assert idx.max() < d.n_verts
+
+
+def test_config_scene_generators_have_the_advertised_shape():
+    c2 = scenes.sponza_class(64, 36)
+    assert 230_000 < c2._nt < 290_000
+    kinds = sorted(e.type for e in c2.emitters)
+    assert kinds.count(abi.EMITTER_AREA) == 4 and kinds.count(abi.EMITTER_POINT) == 2
+    types = {m.type for m in c2.materials}
+    assert abi.BSDF_ROUGHPLASTIC in types and abi.BSDF_DIFFUSE in types
+    c3 = scenes.many_lights(64, 36, n_lights=500, interior_tris=5000)
+    assert sum(e.type == abi.EMITTER_AREA for e in c3.emitters) == 504
+    c4 = scenes.scanned_mesh(64, 36, n=24, env_size=(64, 32))
+    assert c4._nt == 6 * 24 * 24 * 2 + 6 * 8 * 8 * 2 + 2 and c4.envmap is not None
+    assert {abi.BSDF_ROUGHCONDUCTOR, abi.BSDF_DIELECTRIC} <= {m.type for m in c4.materials}
