@@ -93,7 +93,12 @@ __device__ __forceinline__ DHit traverse(const Node4 *__restrict__ nodes, const 
     const float tmin = adaptiveMinT<ANY>(ray.mint, ox, oy, oz);
     float tmax = ray.maxt;
     if (!(tmax > tmin)) return hit;
-    const float idx = 1.0f / ray.dx, idy = 1.0f / ray.dy, idz = 1.0f / ray.dz;
+    /* A zero direction component would give 1/d = inf and 0 * inf = NaN for an origin lying exactly on a slab plane
+     * (rays aimed along an axis at mesh vertices do that); a huge finite reciprocal keeps such a slab "inside". */
+    const float kBig = 0x1p100f, kTiny = 0x1p-100f;
+    const float idx = fabsf(ray.dx) < kTiny ? copysignf(kBig, ray.dx) : 1.0f / ray.dx;
+    const float idy = fabsf(ray.dy) < kTiny ? copysignf(kBig, ray.dy) : 1.0f / ray.dy;
+    const float idz = fabsf(ray.dz) < kTiny ? copysignf(kBig, ray.dz) : 1.0f / ray.dz;
     WoopRay wr; wr.init(ray.dx, ray.dy, ray.dz);
     const float4 *nodes4 = reinterpret_cast<const float4 *>(nodes);
     const float4 *tris4 = reinterpret_cast<const float4 *>(tris);
