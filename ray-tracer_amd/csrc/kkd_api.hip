@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -43,7 +44,6 @@ struct kkd_ctx {
     std::string err;
     std::atomic<int> cancel{0};
     bool haveScene = false;
-    int stackClass = 0;
     HostScene hs;
     DScene ds{};
     /* scene buffers */
@@ -114,9 +114,8 @@ int kkd_scene_upload(kkd_ctx *ctx, const kkd_scene_desc *sd) {
     int code = KKD_ERR_INVALID;
     if (!flattenScene(sd, ctx->hs, ctx->err, &code)) return code;
     HostScene &hs = ctx->hs;
-    if (hs.bvh.info.maxStack <= 32) ctx->stackClass = 0;
-    else if (hs.bvh.info.maxStack <= 96) ctx->stackClass = 1;
-    else return fail(ctx, KKD_ERR_UNSUPPORTED, "acceleration structure deeper than the 96-entry traversal stack");
+    /* the kernels index their stack without a bound check: the builder's worst-case occupancy must fit */
+    if (hs.bvh.info.maxStack > kMaxTraversalStack) return fail(ctx, KKD_ERR_UNSUPPORTED, "acceleration structure deeper than the traversal stack");
     KKD_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
 #define UP(buf, ptr, n) if ((rc = upload(ctx, ctx->buf, ptr, n)) != KKD_OK) return rc;
@@ -195,7 +194,7 @@ static int traceImpl(kkd_ctx *ctx, const void *devRays, uint64_t n, int anyHit, 
     const uint64_t chunk = 1ull << 30;   /* keep grid sizes within 32 bits */
     for (uint64_t off = 0; off < n; off += chunk) {
         const uint64_t m = std::min(chunk, n - off);
-        launchTrace(ctx->stream, ctx->stackClass, ctx->ds, (const DRay *)devRays + off, m, anyHit != 0, count, 1, (DHit *)devOut + off, (DeviceCounters *)ctx->counters.p,
+        launchTrace(ctx->stream, ctx->ds, (const DRay *)devRays + off, m, anyHit != 0, count, 1, (DHit *)devOut + off, (DeviceCounters *)ctx->counters.p,
                     anyHit ? KKD_RAYS_SHADOW : KKD_RAYS_BSDF);
     }
     KKD_HIP(ctx, hipGetLastError());
@@ -297,6 +296,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     bp.nB = nB; bp.nL = nL; bp.hideEmitters = rp->hide_emitters != 0;
     bp.bs = bs; bp.bsPow2 = (bs & (bs - 1)) == 0; bp.nbx = nbx; bp.nby = nby;
     bp.tileIndex = tileIndex; bp.tileCount = tileCount; bp.nTilesMine = nTilesMine; bp.W = W; bp.H = H;
+    { const char *dbg = getenv("KKD_DEBUG"); bp.debug = dbg ? (uint32_t)atoi(dbg) : 0u; }
 
     const uint64_t nBatches = (total + batch - 1) / batch;
     const bool count = (ctx->cfg.flags & KKD_FLAG_COUNT_TRAVERSAL) != 0;
@@ -316,16 +316,16 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         if (ctx->cancel.load()) { cancelled = true; break; }
         bp.w0 = w0; bp.count = (uint32_t)std::min<uint64_t>(batch, total - w0);
         if (timeStages) hipEventRecord(ctx->events[ev++], st);
-        launchPrimary(st, ctx->stackClass, count, ctx->ds, bp, wb.hits, ctr); launches[KKD_STAGE_PRIMARY]++;
+        launchPrimary(st, count, ctx->ds, bp, wb.hits, ctr); launches[KKD_STAGE_PRIMARY]++;
         if (timeStages) hipEventRecord(ctx->events[ev++], st);
         launchShade(st, ctx->ds, bp, wb); launches[KKD_STAGE_SHADE]++;
         if (timeStages) hipEventRecord(ctx->events[ev++], st);
         /* all nB planes are contiguous when count == stride; otherwise trace plane by plane */
-        if (bp.count == bp.stride) { launchTrace(st, ctx->stackClass, ctx->ds, wb.bsdfRays, (uint64_t)S * nB, false, count, 0, wb.bsdfHits, ctr, KKD_RAYS_BSDF); launches[KKD_STAGE_BSDF]++; }
-        else for (uint32_t b = 0; b < nB; ++b) { launchTrace(st, ctx->stackClass, ctx->ds, wb.bsdfRays + (size_t)b * S, bp.count, false, count, 0, wb.bsdfHits + (size_t)b * S, ctr, KKD_RAYS_BSDF); launches[KKD_STAGE_BSDF]++; }
+        if (bp.count == bp.stride) { launchTrace(st, ctx->ds, wb.bsdfRays, (uint64_t)S * nB, false, count, 0, wb.bsdfHits, ctr, KKD_RAYS_BSDF); launches[KKD_STAGE_BSDF]++; }
+        else for (uint32_t b = 0; b < nB; ++b) { launchTrace(st, ctx->ds, wb.bsdfRays + (size_t)b * S, bp.count, false, count, 0, wb.bsdfHits + (size_t)b * S, ctr, KKD_RAYS_BSDF); launches[KKD_STAGE_BSDF]++; }
         if (timeStages) hipEventRecord(ctx->events[ev++], st);
-        if (bp.count == bp.stride) { launchTrace(st, ctx->stackClass, ctx->ds, wb.shadowRays, (uint64_t)S * nL, true, count, 2, wb.occluded, ctr, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++; }
-        else for (uint32_t l = 0; l < nL; ++l) { launchTrace(st, ctx->stackClass, ctx->ds, wb.shadowRays + (size_t)l * S, bp.count, true, count, 2, wb.occluded + (size_t)l * S, ctr, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++; }
+        if (bp.count == bp.stride) { launchTrace(st, ctx->ds, wb.shadowRays, (uint64_t)S * nL, true, count, 2, wb.occluded, ctr, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++; }
+        else for (uint32_t l = 0; l < nL; ++l) { launchTrace(st, ctx->ds, wb.shadowRays + (size_t)l * S, bp.count, true, count, 2, wb.occluded + (size_t)l * S, ctr, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++; }
         if (timeStages) hipEventRecord(ctx->events[ev++], st);
         launchResolve(st, ctx->ds, bp, wb, film, ctr); launches[KKD_STAGE_RESOLVE]++;
         if (timeStages) hipEventRecord(ctx->events[ev++], st);

@@ -6,6 +6,9 @@
 namespace kkd {
 
 /* per ray class (KKD_RAYS_PRIMARY / _BSDF / _SHADOW) */
+/* traversal stack capacity per lane: kStackLds entries in LDS + kStackOverflow in private memory (kkd_trace.h) */
+static constexpr int kMaxTraversalStack = 16 + 80;
+
 struct DeviceCounters { unsigned long long samples, pad; unsigned long long rays[3], nodes[3], tris[3]; };
 
 /* One batch = work items [w0, w0 + count) of the render; see mapWorkItem() in kkd_kernels.hip. */
@@ -16,6 +19,7 @@ struct BatchParams {
     uint32_t nB, nL, hideEmitters;
     uint32_t bs, bsPow2, nbx, nby, tileIndex, tileCount, nTilesMine;
     int32_t W, H;
+    uint32_t debug;                  /* developer ablation bits from $KKD_DEBUG: 1 = no film atomics, 2 = no BSDF-hit evaluation */
 };
 
 /* SoA work buffers of one batch (all device memory). */
@@ -31,11 +35,10 @@ struct WaveBuffers {
     float4 *lrec;        /* MIS-weighted light contribution    [nL * stride] */
 };
 
-/* stackClass: 0 = 32-entry LDS stack, 256-thread blocks; 1 = 96-entry stack, 64-thread blocks */
-void launchPrimary(hipStream_t st, int stackClass, bool count, const DScene &sc, const BatchParams &bp, DHit *hits, DeviceCounters *ctr);
+void launchPrimary(hipStream_t st, bool count, const DScene &sc, const BatchParams &bp, DHit *hits, DeviceCounters *ctr);
 /* outMode: 0 = DHit with LeafTri slot, 1 = DHit with global primitive id, 2 = uint32 occlusion flags (anyHit only) */
 /* rayClass: which DeviceCounters slot the launch accounts to */
-void launchTrace(hipStream_t st, int stackClass, const DScene &sc, const DRay *rays, uint64_t n, bool anyHit, bool count, int outMode, void *out, DeviceCounters *ctr, int rayClass);
+void launchTrace(hipStream_t st, const DScene &sc, const DRay *rays, uint64_t n, bool anyHit, bool count, int outMode, void *out, DeviceCounters *ctr, int rayClass);
 void launchShade(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb);
 void launchResolve(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb, float *film, DeviceCounters *ctr);
 

@@ -198,6 +198,70 @@ __global__ void __launch_bounds__(256) kShade(DScene sc, BatchParams bp, WaveBuf
     wb.accum[i] = accum;
 }
 
+/* ---- filtered splat of 64 samples of one pixel (ImageBlock::put, reduced across the wave) -----------------------
+ * Every lane holds one sample of pixel (X, Y); its footprint lies inside the (2B+1)^2 window around the pixel, i.e.
+ * NV = (2B+1)^2 * 5 film words.  The words are summed over the 64 lanes by a halving butterfly: at each of the six
+ * steps a lane hands one half of the words it still holds to a partner and adds the partner's other half, so 64 words
+ * cost 63 exchanges (v_permlane32_swap / v_permlane16_swap / DPP row_mirror, row_half_mirror, quad_perm) instead of
+ * 64 x 6, and lane l ends up owning the total of word (pass * 64 + l): one global_atomic_add_f32 per lane and pass,
+ * contiguous within a film row. */
+__device__ __forceinline__ void swap32(float &a, float &b) {   /* a.lanes[32:63] <-> b.lanes[0:31] */
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap16(float &a, float &b) {   /* odd rows of a <-> even rows of b */
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+template <int CTRL> __device__ __forceinline__ float dppMove(float v) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, true));
+}
+template <int N, int CTRL> __device__ __forceinline__ void butterflyDpp(float *a, bool upper) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float send = upper ? a[i] : a[i + N], keep = upper ? a[i + N] : a[i];
+        a[i] = keep + dppMove<CTRL>(send);
+    }
+}
+
+template <int B>
+__device__ __forceinline__ void splatWave64(float *__restrict__ film, const float *sfilter, float radius, float scale,
+                                            int X, int Y, int W, int H, float posx, float posy, const float *val, bool noAtomics) {
+    constexpr int WIN = 2 * B + 1, NV = WIN * WIN * 5, NPASS = (NV + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    const int lox = (int)ceilf(posx - radius), hix = (int)floorf(posx + radius);
+    const int loy = (int)ceilf(posy - radius), hiy = (int)floorf(posy + radius);
+    float fx[WIN], fy[WIN];
+#pragma unroll
+    for (int i = 0; i < WIN; ++i) {
+        const int xi = X - B + i, yi = Y - B + i;
+        fx[i] = (xi >= lox && xi <= hix) ? sfilter[min((int)fabsf(((float)xi - posx) * scale), 31)] : 0.f;
+        fy[i] = (yi >= loy && yi <= hiy) ? sfilter[min((int)fabsf(((float)yi - posy) * scale), 31)] : 0.f;
+    }
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+        float a[64];
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const int k = pass * 64 + i;
+            a[i] = k < NV ? fx[(k / 5) % WIN] * fy[(k / 5) / WIN] * val[k % 5] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { swap32(a[i], a[i + 32]); a[i] += a[i + 32]; }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { swap16(a[i], a[i + 16]); a[i] += a[i + 16]; }
+        butterflyDpp<8, 0x140>(a, (lane & 8) != 0);   /* row_mirror: partner differs in bit 3          */
+        butterflyDpp<4, 0x141>(a, (lane & 4) != 0);   /* row_half_mirror: partner differs in bit 2     */
+        butterflyDpp<2, 0x4E>(a, (lane & 2) != 0);    /* quad_perm [2,3,0,1]                           */
+        butterflyDpp<1, 0xB1>(a, (lane & 1) != 0);    /* quad_perm [1,0,3,2]                           */
+        const int k = pass * 64 + lane;
+        if (k < NV && a[0] != 0.f) {
+            const int c = k % 5, pix = k / 5, xo = X - B + pix % WIN, yo = Y - B + pix / WIN;
+            if (xo >= 0 && xo < W && yo >= 0 && yo < H) { if (!noAtomics) atomicAdd(film + ((size_t)yo * W + xo) * 5 + c, a[0]); else if (a[0] == 12345.678f) film[0] = a[0]; }
+        }
+    }
+}
+
 /* ---- K5: resolve + splat ---------------------------------------------------------------------------- */
 __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveBuffers wb, float *__restrict__ film, DeviceCounters *ctr) {
     __shared__ float sfilter[32];
@@ -217,7 +281,7 @@ __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveB
         const float cB = nB / (float)(nB + nL), cL = nL / (float)(nB + nL);
         for (uint32_t b = 0; b < nB; ++b) {                        /* kk/direct.cpp:105-123 + :167-171 */
             const float4 rec = wb.brec0[(size_t)b * bp.stride + i];
-            if (rec.w == 0.f) continue;
+            if (rec.w == 0.f || (bp.debug & 2u)) continue;
             const DRay r = wb.bsdfRays[(size_t)b * bp.stride + i];
             const DHit h = wb.bsdfHits[(size_t)b * bp.stride + i];
             const f3 rd(r.dx, r.dy, r.dz);
@@ -259,6 +323,16 @@ __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveB
     const uint32_t g = bp.g, j = threadIdx.x & (g - 1u);
     /* every lane of a group maps to the same pixel, also the inactive ones */
     const int X = s.X, Y = s.Y, W = bp.W, H = bp.H;
+    if (g == 64u && b <= 3) {   /* wave-uniform: the whole wave holds samples of one pixel */
+        switch (b) {
+            case 0: splatWave64<0>(film, sfilter, radius, scale, X, Y, W, H, posx, posy, val, (bp.debug & 1u) != 0); break;
+            case 1: splatWave64<1>(film, sfilter, radius, scale, X, Y, W, H, posx, posy, val, (bp.debug & 1u) != 0); break;
+            case 2: splatWave64<2>(film, sfilter, radius, scale, X, Y, W, H, posx, posy, val, (bp.debug & 1u) != 0); break;
+            default: splatWave64<3>(film, sfilter, radius, scale, X, Y, W, H, posx, posy, val, (bp.debug & 1u) != 0); break;
+        }
+        if (ctr) countRays(s.active, &ctr->samples);
+        return;
+    }
     float keep = 0.f; int k = 0;
     for (int wy = 0; wy < win; ++wy) {
         const int yi = Y - b + wy;
@@ -292,30 +366,24 @@ __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveB
 /* ---- host launchers ---------------------------------------------------------------------------------- */
 static inline uint32_t blocksFor(uint64_t n, uint32_t block) { return (uint32_t)((n + block - 1) / block); }
 
-void launchPrimary(hipStream_t st, int stackClass, bool count, const DScene &sc, const BatchParams &bp, DHit *hits, DeviceCounters *ctr) {
-    if (stackClass == 0) {
-        if (count) hipLaunchKernelGGL((kPrimary<true, 32, 256>), dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, hits, ctr);
-        else hipLaunchKernelGGL((kPrimary<false, 32, 256>), dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, hits, ctr);
-    } else {
-        if (count) hipLaunchKernelGGL((kPrimary<true, 96, 64>), dim3(blocksFor(bp.count, 64)), dim3(64), 0, st, sc, bp, hits, ctr);
-        else hipLaunchKernelGGL((kPrimary<false, 96, 64>), dim3(blocksFor(bp.count, 64)), dim3(64), 0, st, sc, bp, hits, ctr);
-    }
+void launchPrimary(hipStream_t st, bool count, const DScene &sc, const BatchParams &bp, DHit *hits, DeviceCounters *ctr) {
+    if (count) hipLaunchKernelGGL((kPrimary<true, kStackLds, 256>), dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, hits, ctr);
+    else hipLaunchKernelGGL((kPrimary<false, kStackLds, 256>), dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, hits, ctr);
 }
 
 template <bool ANY, bool COUNT, int OUT>
-static void launchTraceT(hipStream_t st, int stackClass, const DScene &sc, const DRay *rays, uint64_t n, void *out, DeviceCounters *ctr, int cls) {
-    if (stackClass == 0) hipLaunchKernelGGL((kTrace<ANY, COUNT, OUT, 32, 256>), dim3(blocksFor(n, 256)), dim3(256), 0, st, sc.nodes, sc.tris, rays, n, out, ctr, cls);
-    else hipLaunchKernelGGL((kTrace<ANY, COUNT, OUT, 96, 64>), dim3(blocksFor(n, 64)), dim3(64), 0, st, sc.nodes, sc.tris, rays, n, out, ctr, cls);
+static void launchTraceT(hipStream_t st, const DScene &sc, const DRay *rays, uint64_t n, void *out, DeviceCounters *ctr, int cls) {
+    hipLaunchKernelGGL((kTrace<ANY, COUNT, OUT, kStackLds, 256>), dim3(blocksFor(n, 256)), dim3(256), 0, st, sc.nodes, sc.tris, rays, n, out, ctr, cls);
 }
 
-void launchTrace(hipStream_t st, int stackClass, const DScene &sc, const DRay *rays, uint64_t n, bool anyHit, bool count, int outMode, void *out, DeviceCounters *ctr, int cls) {
+void launchTrace(hipStream_t st, const DScene &sc, const DRay *rays, uint64_t n, bool anyHit, bool count, int outMode, void *out, DeviceCounters *ctr, int cls) {
     if (n == 0) return;
     if (anyHit) {
-        if (outMode == 2) { if (count) launchTraceT<true, true, 2>(st, stackClass, sc, rays, n, out, ctr, cls); else launchTraceT<true, false, 2>(st, stackClass, sc, rays, n, out, ctr, cls); }
-        else { if (count) launchTraceT<true, true, 1>(st, stackClass, sc, rays, n, out, ctr, cls); else launchTraceT<true, false, 1>(st, stackClass, sc, rays, n, out, ctr, cls); }
+        if (outMode == 2) { if (count) launchTraceT<true, true, 2>(st, sc, rays, n, out, ctr, cls); else launchTraceT<true, false, 2>(st, sc, rays, n, out, ctr, cls); }
+        else { if (count) launchTraceT<true, true, 1>(st, sc, rays, n, out, ctr, cls); else launchTraceT<true, false, 1>(st, sc, rays, n, out, ctr, cls); }
     } else {
-        if (outMode == 0) { if (count) launchTraceT<false, true, 0>(st, stackClass, sc, rays, n, out, ctr, cls); else launchTraceT<false, false, 0>(st, stackClass, sc, rays, n, out, ctr, cls); }
-        else { if (count) launchTraceT<false, true, 1>(st, stackClass, sc, rays, n, out, ctr, cls); else launchTraceT<false, false, 1>(st, stackClass, sc, rays, n, out, ctr, cls); }
+        if (outMode == 0) { if (count) launchTraceT<false, true, 0>(st, sc, rays, n, out, ctr, cls); else launchTraceT<false, false, 0>(st, sc, rays, n, out, ctr, cls); }
+        else { if (count) launchTraceT<false, true, 1>(st, sc, rays, n, out, ctr, cls); else launchTraceT<false, false, 1>(st, sc, rays, n, out, ctr, cls); }
     }
 }
 

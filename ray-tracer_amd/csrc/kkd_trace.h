@@ -8,15 +8,17 @@
  * acceptance interval, the hit record (t, barycentrics of vertices 1 and 2, primitive).
  *
  * Memory shape: a node visit is eight 16-byte loads of one 128-byte line (Node4), a triangle test is
- * three 16-byte loads (LeafTri); the stack never leaves LDS (index = slot * BLOCK + thread, so the
- * two 32-lane halves of a wave never collide on a bank).
+ * three 16-byte loads (LeafTri); the first STACK entries of a lane's stack live in LDS (index = slot * BLOCK +
+ * thread, so the two 32-lane halves of a wave never collide on a bank) and only deeper entries, which the SAH
+ * trees of the configs almost never reach, spill to a per-lane private array of kStackOverflow words.
  */
 #pragma once
 #include "kkd_types.h"
 
 namespace kkd {
 
-struct TraceCounters { unsigned long long rays, nodes, tris; };
+static constexpr int kStackLds = 16;        /* LDS-resident stack entries per lane           */
+static constexpr int kStackOverflow = 80;   /* further entries in private (scratch) memory   */
 
 __device__ __forceinline__ float selc(float x, float y, float z, int k) { return k == 0 ? x : (k == 1 ? y : z); }
 
@@ -103,7 +105,9 @@ __device__ __forceinline__ DHit traverse(const Node4 *__restrict__ nodes, const 
     const float4 *nodes4 = reinterpret_cast<const float4 *>(nodes);
     const float4 *tris4 = reinterpret_cast<const float4 *>(tris);
     const int tid = threadIdx.x;
+    uint32_t ovf[kStackOverflow];
     int sp = 0;
+#define KKD_PUSH(V) { if (sp < STACK) sstack[sp * BLOCK + tid] = (V); else ovf[sp - STACK] = (V); ++sp; }
     uint32_t cur = 0;   /* root */
     /* every wave leaves this loop: the walk is finite on a tree, and the step bound ends it on a malformed one */
     for (int guard = 1 << 24; guard > 0; --guard) {
@@ -131,9 +135,9 @@ __device__ __forceinline__ DHit traverse(const Node4 *__restrict__ nodes, const 
             KKD_CSWAP(d0, c0, d1, c1) KKD_CSWAP(d2, c2, d3, c3) KKD_CSWAP(d0, c0, d2, c2) KKD_CSWAP(d1, c1, d3, c3) KKD_CSWAP(d1, c1, d2, c2)
 #undef KKD_CSWAP
             if (d0 < kInf) {
-                if (d3 < kInf) sstack[(sp++) * BLOCK + tid] = c3;
-                if (d2 < kInf) sstack[(sp++) * BLOCK + tid] = c2;
-                if (d1 < kInf) sstack[(sp++) * BLOCK + tid] = c1;
+                if (d3 < kInf) KKD_PUSH(c3)
+                if (d2 < kInf) KKD_PUSH(c2)
+                if (d1 < kInf) KKD_PUSH(c1)
                 cur = c0;
                 continue;
             }
@@ -151,8 +155,10 @@ __device__ __forceinline__ DHit traverse(const Node4 *__restrict__ nodes, const 
             }
         }
         if (sp == 0) break;
-        cur = sstack[(--sp) * BLOCK + tid];
+        --sp;
+        cur = sp < STACK ? sstack[sp * BLOCK + tid] : ovf[sp - STACK];
     }
+#undef KKD_PUSH
     return hit;
 }
 
