@@ -167,6 +167,15 @@ int kkd_accel_info(kkd_ctx *ctx, uint32_t *node_bytes, uint32_t *tri_bytes, uint
     return KKD_OK;
 }
 
+static DeviceCounters sumShards(const std::vector<DeviceCounters> &shards) {
+    DeviceCounters c; std::memset(&c, 0, sizeof(c));
+    for (const DeviceCounters &s : shards) {
+        c.samples += s.samples;
+        for (int k = 0; k < 3; ++k) { c.rays[k] += s.rays[k]; c.nodes[k] += s.nodes[k]; c.tris[k] += s.tris[k]; }
+    }
+    return c;
+}
+
 static void fillCounterStats(kkd_stats *stats, const DeviceCounters &c, bool counted) {
     stats->samples = c.samples;
     stats->rays_closest = c.rays[KKD_RAYS_PRIMARY] + c.rays[KKD_RAYS_BSDF]; stats->rays_shadow = c.rays[KKD_RAYS_SHADOW];
@@ -186,8 +195,8 @@ static void fillCounterStats(kkd_stats *stats, const DeviceCounters &c, bool cou
 static int traceImpl(kkd_ctx *ctx, const void *devRays, uint64_t n, int anyHit, void *devOut, bool count, kkd_stats *stats) {
     if (!ctx->haveScene) return fail(ctx, KKD_ERR_INVALID, "no scene uploaded");
     KKD_HIP(ctx, hipSetDevice(ctx->device));
-    KKD_HIP(ctx, ctx->counters.ensure(sizeof(DeviceCounters)));
-    KKD_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, sizeof(DeviceCounters), ctx->stream));
+    KKD_HIP(ctx, ctx->counters.ensure(kCounterShards * sizeof(DeviceCounters)));
+    KKD_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, kCounterShards * sizeof(DeviceCounters), ctx->stream));
     hipEvent_t e0, e1;
     KKD_HIP(ctx, hipEventCreate(&e0)); KKD_HIP(ctx, hipEventCreate(&e1));
     KKD_HIP(ctx, hipEventRecord(e0, ctx->stream));
@@ -199,9 +208,10 @@ static int traceImpl(kkd_ctx *ctx, const void *devRays, uint64_t n, int anyHit, 
     }
     KKD_HIP(ctx, hipGetLastError());
     KKD_HIP(ctx, hipEventRecord(e1, ctx->stream));
-    DeviceCounters c;
-    KKD_HIP(ctx, hipMemcpyAsync(&c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<DeviceCounters> shards(kCounterShards);
+    KKD_HIP(ctx, hipMemcpyAsync(shards.data(), ctx->counters.p, kCounterShards * sizeof(DeviceCounters), hipMemcpyDeviceToHost, ctx->stream));
     KKD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const DeviceCounters c = sumShards(shards);
     float ms = 0.f;
     KKD_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
     hipEventDestroy(e0); hipEventDestroy(e1);
@@ -266,7 +276,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     const uint32_t g = std::min(64u, pow2ceil(rp->spp)), chunks = (rp->spp + g - 1) / g;
     uint32_t gShift = 0; while ((1u << gShift) < g) ++gShift;
     const uint64_t total = (uint64_t)nTilesMine * bs * bs * chunks * g;
-    uint64_t batch = ctx->cfg.max_samples_in_flight ? ctx->cfg.max_samples_in_flight : (1ull << 21);
+    uint64_t batch = ctx->cfg.max_samples_in_flight ? ctx->cfg.max_samples_in_flight : (1ull << 23);
     batch = std::max<uint64_t>(256, (batch + 255) / 256 * 256);
     batch = std::min<uint64_t>(batch, 1ull << 28);
     batch = std::min<uint64_t>(batch, std::max<uint64_t>(256, (total + 255) / 256 * 256));
@@ -278,7 +288,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     need(ctx->hits, S * sizeof(DHit)); need(ctx->accum, S * 16); need(ctx->refN, S * 16);
     need(ctx->bsdfRays, S * nB * sizeof(DRay)); need(ctx->bsdfHits, S * nB * sizeof(DHit)); need(ctx->brec0, S * nB * 16);
     need(ctx->shadowRays, S * nL * sizeof(DRay)); need(ctx->occluded, S * nL * 4); need(ctx->lrec, S * nL * 16);
-    need(ctx->counters, sizeof(DeviceCounters));
+    need(ctx->counters, kCounterShards * sizeof(DeviceCounters));
     if (!devFilm) need(ctx->film, (size_t)W * H * 5 * sizeof(float));
     if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? KKD_ERR_NOMEM : KKD_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
     float *film = devFilm ? devFilm : (float *)ctx->film.p;
@@ -307,7 +317,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
 
     hipStream_t st = ctx->stream;
     KKD_HIP(ctx, hipMemsetAsync(film, 0, (size_t)W * H * 5 * sizeof(float), st));
-    KKD_HIP(ctx, hipMemsetAsync(ctr, 0, sizeof(DeviceCounters), st));
+    KKD_HIP(ctx, hipMemsetAsync(ctr, 0, kCounterShards * sizeof(DeviceCounters), st));
     KKD_HIP(ctx, hipEventRecord(ctx->events[0], st));
     size_t ev = 2;
     uint64_t launches[5] = { 0, 0, 0, 0, 0 };
@@ -332,9 +342,10 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     }
     KKD_HIP(ctx, hipGetLastError());
     KKD_HIP(ctx, hipEventRecord(ctx->events[1], st));
-    DeviceCounters c;
-    KKD_HIP(ctx, hipMemcpyAsync(&c, ctr, sizeof(c), hipMemcpyDeviceToHost, st));
+    std::vector<DeviceCounters> shards(kCounterShards);
+    KKD_HIP(ctx, hipMemcpyAsync(shards.data(), ctr, kCounterShards * sizeof(DeviceCounters), hipMemcpyDeviceToHost, st));
     KKD_HIP(ctx, hipStreamSynchronize(st));
+    const DeviceCounters c = sumShards(shards);
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         float ms = 0.f;

@@ -59,6 +59,7 @@ __device__ __forceinline__ DRay primaryRay(const DScene &sc, const BatchParams &
     return sensorRay(sc.sensor, sx, sy);
 }
 
+__device__ __forceinline__ DeviceCounters *counterShard(DeviceCounters *ctr) { return ctr + (blockIdx.x % kCounterShards); }
 __device__ __forceinline__ void countRays(bool traced, unsigned long long *counter) {
     const unsigned long long m = __ballot(traced);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(counter, (unsigned long long)__popcll(m));
@@ -81,6 +82,7 @@ __global__ void __launch_bounds__(BLOCK) kPrimary(DScene sc, BatchParams bp, DHi
     uint32_t nn = 0, nt = 0;
     const DHit h = traverse<false, COUNT, STACK, BLOCK>(sc.nodes, sc.tris, ray, sstack, nn, nt);
     if (i < bp.count) hits[i] = h;
+    ctr = counterShard(ctr);
     countRays(s.active, &ctr->rays[KKD_RAYS_PRIMARY]);
     if (COUNT) countTraversal(nn, nt, ctr, KKD_RAYS_PRIMARY);
 }
@@ -104,6 +106,7 @@ __global__ void __launch_bounds__(BLOCK) kTrace(const Node4 *__restrict__ nodes,
         }
     }
     if (ctr) {
+        ctr = counterShard(ctr);
         const bool traced = i < n && ray.maxt > adaptiveMinT<ANY>(ray.mint, ray.ox, ray.oy, ray.oz);
         countRays(traced, &ctr->rays[cls]);
         if (COUNT) countTraversal(nn, nt, ctr, cls);
@@ -330,7 +333,7 @@ __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveB
             case 2: splatWave64<2>(film, sfilter, radius, scale, X, Y, W, H, posx, posy, val, (bp.debug & 1u) != 0); break;
             default: splatWave64<3>(film, sfilter, radius, scale, X, Y, W, H, posx, posy, val, (bp.debug & 1u) != 0); break;
         }
-        if (ctr) countRays(s.active, &ctr->samples);
+        if (ctr) countRays(s.active, &counterShard(ctr)->samples);
         return;
     }
     float keep = 0.f; int k = 0;
@@ -360,7 +363,7 @@ __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveB
             }
         }
     }
-    if (ctr) countRays(s.active, &ctr->samples);
+    if (ctr) countRays(s.active, &counterShard(ctr)->samples);
 }
 
 /* ---- host launchers ---------------------------------------------------------------------------------- */
