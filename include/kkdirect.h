@@ -267,6 +267,16 @@ int kkd_trace_counted(kkd_ctx *ctx, const float *rays, uint64_t n, int any_hit, 
  * records: 8-byte KDNode, 4-byte index, 48-byte TriAccel, src/librender/skdtree.cpp:77-79). */
 int kkd_accel_info(kkd_ctx *ctx, uint32_t *node_bytes, uint32_t *tri_bytes, uint64_t *n_nodes, uint64_t *n_leaf_tris);
 
+/* Host-only probes of the tables kkd_scene_upload builds (no GPU needed; used by the CPU tests).
+ * Rough-dielectric transmittance for one (distribution, alpha, eta): 100 knots at cosTheta^(1/4) = i/99 and the
+ * diffuse transmittance, i.e. what RoughTransmittance yields after setEta()/setAlpha() (src/bsdfs/rtrans.h:183-280)
+ * from the data file written by src/utils/rdielprec.cpp:66-190. */
+int kkd_probe_rough_transmittance(int distribution, float alpha, float eta, float *trans100, float *diffuse_transmittance);
+
+/* Discretised reconstruction filter: 32 table values, scale factor and border size as computed by
+ * ReconstructionFilter::configure (src/libcore/rfilter.cpp:37-55) for the filters of src/rfilters/. */
+int kkd_probe_rfilter(int rfilter_type, float radius, const float *param2, float *values32, float *scale_factor, int *border);
+
 /* Asynchronous, thread-safe: replaces SamplingIntegrator::cancel (src/librender/integrator.cpp:90-93). */
 void kkd_request_cancel(kkd_ctx *ctx);
 

@@ -90,6 +90,21 @@ kkd_ctx *kkd_create(const kkd_config *cfg) {
     return ctx;
 }
 
+int kkd_probe_rough_transmittance(int distribution, float alpha, float eta, float *trans100, float *diffuse_transmittance) {
+    if (!trans100 || !diffuse_transmittance || (distribution != KKD_DISTR_BECKMANN && distribution != KKD_DISTR_GGX) || !(alpha > 0.f) || !(eta > 0.f))
+        return KKD_ERR_INVALID;
+    roughTransmittanceTable(distribution, alpha, eta, trans100, diffuse_transmittance);
+    return KKD_OK;
+}
+
+int kkd_probe_rfilter(int rfilter_type, float radius, const float *param2, float *values32, float *scale_factor, int *border) {
+    if (!param2 || !values32 || !scale_factor || !border || rfilter_type < 0 || rfilter_type > KKD_RFILTER_LANCZOS || !(radius > 0.f)) return KKD_ERR_INVALID;
+    DFilter f;
+    configureFilter(rfilter_type, radius, param2, f);
+    std::memcpy(values32, f.values, sizeof(f.values)); *scale_factor = f.scaleFactor; *border = f.border;
+    return KKD_OK;
+}
+
 const char *kkd_last_error(kkd_ctx *ctx) { return ctx ? ctx->err.c_str() : g_createError.c_str(); }
 
 void kkd_request_cancel(kkd_ctx *ctx) { if (ctx) ctx->cancel.store(1); }

@@ -92,6 +92,8 @@ ENTRY_POINTS = {
     "kkd_trace_device": (C.c_int, [C.c_void_p, C.c_void_p, u64, C.c_int, C.c_void_p, C.POINTER(Stats)]),
     "kkd_trace_counted": (C.c_int, [C.c_void_p, pf32, u64, C.c_int, C.POINTER(Hit), C.POINTER(Stats)]),
     "kkd_accel_info": (C.c_int, [C.c_void_p, pu32, pu32, C.POINTER(u64), C.POINTER(u64)]),
+    "kkd_probe_rough_transmittance": (C.c_int, [C.c_int, C.c_float, C.c_float, pf32, pf32]),
+    "kkd_probe_rfilter": (C.c_int, [C.c_int, C.c_float, pf32, pf32, pf32, C.POINTER(C.c_int)]),
     "kkd_request_cancel": (None, [C.c_void_p]),
     "kkd_last_error": (C.c_char_p, [C.c_void_p]),
     "kkd_destroy": (None, [C.c_void_p]),

@@ -110,3 +110,26 @@ def test_config_scene_generators_have_the_advertised_shape():
     c4 = scenes.scanned_mesh(64, 36, n=24, env_size=(64, 32))
     assert c4._nt == 6 * 24 * 24 * 2 + 6 * 8 * 8 * 2 + 2 and c4.envmap is not None
     assert {abi.BSDF_ROUGHCONDUCTOR, abi.BSDF_DIELECTRIC} <= {m.type for m in c4.materials}
+
+
+def test_product_tables_match_the_oracle():
+    """The library builds its own rough-transmittance and filter tables (it never calls the oracle); both are
+    restatements of the same reference definitions and must agree."""
+    import kkoracle
+    lib = kkdirect.load_library()
+    for distr, alpha, eta in ((abi.DISTR_BECKMANN, 0.1, 1.49 / 1.000277), (abi.DISTR_GGX, 0.3, 1.5), (abi.DISTR_BECKMANN, 0.2, 1.0 / 1.49)):
+        t = np.zeros(100, np.float32); d = np.zeros(1, np.float32)
+        assert lib.kkd_probe_rough_transmittance(distr, alpha, eta, t.ctypes.data_as(abi.pf32), d.ctypes.data_as(abi.pf32)) == 0
+        to, do = kkoracle.rough_transmittance(distr, alpha, eta)
+        # reference tolerance for this table: 1e-3 absolute (src/tests/test_rtrans.cpp:154-190)
+        np.testing.assert_allclose(t, to, atol=2e-4)
+        assert abs(float(d[0]) - do) < 2e-4
+    for ftype, radius, param in ((abi.RFILTER_GAUSSIAN, 2.0, (0.5, 0.0)), (abi.RFILTER_BOX, 0.5 + 1e-5, (0, 0)), (abi.RFILTER_TENT, 1.0, (0, 0)),
+                                 (abi.RFILTER_MITCHELL, 2.0, (1 / 3.0, 1 / 3.0)), (abi.RFILTER_CATMULLROM, 2.0, (0, 0)), (abi.RFILTER_LANCZOS, 3.0, (3.0, 0))):
+        v = np.zeros(32, np.float32); sc = np.zeros(1, np.float32); b = C.c_int()
+        p = np.asarray(param, np.float32)
+        assert lib.kkd_probe_rfilter(ftype, radius, p.ctypes.data_as(abi.pf32), v.ctypes.data_as(abi.pf32), sc.ctypes.data_as(abi.pf32), C.byref(b)) == 0
+        vo, so, bo = kkoracle.rfilter_table(ftype, radius, param)
+        np.testing.assert_allclose(v, vo, rtol=1e-6, atol=1e-7)
+        assert abs(float(sc[0]) - so) < 1e-6 and b.value == bo
+    assert lib.kkd_probe_rough_transmittance(abi.DISTR_PHONG, 0.1, 1.5, t.ctypes.data_as(abi.pf32), d.ctypes.data_as(abi.pf32)) == abi.KKD_ERR_INVALID
