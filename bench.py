@@ -42,14 +42,14 @@ def make_workload(name, scale):
     raise SystemExit("unknown workload " + name)
 
 
-def stage_bytes(st, n_b, n_l, per_ray):
+def stage_bytes(st, n_b, n_l, per_ray, node_bytes=64.0, tri_bytes=48.0):
     """Algorithmic bytes per kernel stage for one render ('algorithmic bytes').
     per_ray[k] = (nodes/ray, tris/ray) measured by the counting build of the same traversal."""
     rays = list(st.class_rays)
     io = (16.0, 48.0, 36.0)   # primary: hit write; bsdf: ray read + hit write; shadow: ray read + flag write
-    trav = [rays[k] * (io[k] + per_ray[k][0] * 128.0 + per_ray[k][1] * 48.0) for k in range(3)]
+    trav = [rays[k] * (io[k] + per_ray[k][0] * node_bytes + per_ray[k][1] * tri_bytes) for k in range(3)]
     s = float(st.samples)
-    shade = s * (16 + 48 + 12 + 36 + 32 + 128 + 64 + 12 + 36 + 16 + 16 + n_b * 48 + n_l * 48)
+    shade = s * (16 + tri_bytes + 12 + 36 + 32 + 128 + 64 + 12 + 36 + 16 + 16 + n_b * 48 + n_l * 48)
     resolve = s * (16 + 16 + n_b * 64 + n_l * 20 + 125.0 / 64.0 * 8.0)
     return [trav[0], shade, trav[1], trav[2], resolve]
 
@@ -138,7 +138,8 @@ def main():
         per_ray = [(cst.class_nodes[k] / max(1, cst.class_rays[k]), cst.class_tris[k] / max(1, cst.class_rays[k])) for k in range(3)]
         stage_s = [sum(s.stage_seconds[k] for s in stats) for k in range(5)]
         stage_n = [sum(s.stage_launches[k] for s in stats) for k in range(5)]
-        bytes_k = [sum(stage_bytes(s, n_b, n_l, per_ray)[k] for s in stats) for k in range(5)]
+        acc = ctx.accel_info()
+        bytes_k = [sum(stage_bytes(s, n_b, n_l, per_ray, acc["node_bytes"], acc["tri_bytes"])[k] for s in stats) for k in range(5)]
         dom = int(np.argmax(stage_s))
         avg_launch_s = stage_s[dom] / max(1, stage_n[dom])
         achieved = bytes_k[dom] / max(1, stage_n[dom]) / max(avg_launch_s, 1e-12) / 1e9

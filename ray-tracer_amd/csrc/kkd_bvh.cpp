@@ -36,6 +36,9 @@ struct Box {
 
 struct Prim { Box box; float c[3]; uint32_t id; };
 
+/* builder-internal uncompressed 4-wide node */
+struct Node4F { float minx[4], miny[4], minz[4], maxx[4], maxy[4], maxz[4]; uint32_t child[4]; int nk; };
+
 struct Node2 { Box box; uint32_t left, right; uint32_t start, count; /* count > 0: leaf */ };
 
 struct Builder {
@@ -117,7 +120,7 @@ struct Builder {
 
 struct Collapser {
     const Builder &b; const float *pos; const uint32_t *idx; const uint32_t *shapeOfPrim;
-    std::vector<Node4> &out; std::vector<LeafTri> &tris; BVH4::Info &info;
+    std::vector<Node4F> &out; std::vector<LeafTri> &tris; BVH4::Info &info;
 
     uint32_t emitLeaf(const Node2 &n) {
         const uint32_t start = (uint32_t)tris.size();
@@ -152,11 +155,10 @@ struct Collapser {
         }
         const uint32_t me = (uint32_t)out.size();
         out.emplace_back();
-        Node4 nd;
+        Node4F nd; nd.nk = nk;
         for (int k = 0; k < 4; ++k) {
-            /* empty slot: min = max = +inf makes every slab interval empty for any ray direction */
             nd.minx[k] = nd.miny[k] = nd.minz[k] = INFINITY; nd.maxx[k] = nd.maxy[k] = nd.maxz[k] = INFINITY;
-            nd.child[k] = 0; nd.pad[k] = 0;
+            nd.child[k] = 0;   /* empty slot */
         }
         /* a visit pushes at most nk-1 siblings */
         const int stackHere = stackAbove + nk - 1;
@@ -173,6 +175,43 @@ struct Collapser {
 };
 
 } /* namespace */
+
+/* 8-bit grid encoding of a node's child boxes (layout: kkd_types.h).  Per axis: origin = min over the children,
+ * scale = smallest power of two with extent <= 255 * scale; min planes round down, max planes up, and every plane is
+ * checked through the kernel's own decode, fmaf(q, scale, origin), so the decoded box always encloses the true one. */
+static inline float decodePlane(uint8_t q, float scale, float origin) { return std::fmaf((float)q, scale, origin); }
+
+static void quantizeNode(const Node4F &n, Node4 &out) {
+    std::memset(&out, 0, sizeof(out));
+    const float *mins[3] = { n.minx, n.miny, n.minz }, *maxs[3] = { n.maxx, n.maxy, n.maxz };
+    uint8_t *qmins[3] = { out.qminx, out.qminy, out.qminz }, *qmaxs[3] = { out.qmaxx, out.qmaxy, out.qmaxz };
+    float origin[3]; uint8_t expo[3];
+    for (int a = 0; a < 3; ++a) {
+        float lo = INFINITY, hi = -INFINITY;
+        for (int k = 0; k < n.nk; ++k) { lo = std::min(lo, mins[a][k]); hi = std::max(hi, maxs[a][k]); }
+        origin[a] = lo;
+        const float extent = hi - lo;
+        int e = 0;                                   /* scale = 2^e */
+        if (extent > 0.f) { std::frexp(extent / 255.0f, &e); }   /* extent/255 = m * 2^e, m in [0.5,1) => 2^e >= extent/255 */
+        else e = -126;
+        e = std::max(-126, std::min(127, e));
+        float scale = std::ldexp(1.0f, e);
+        /* make sure the top of the range is reachable after float rounding of the decode */
+        while (e < 127 && decodePlane(255, scale, lo) < hi) { ++e; scale = std::ldexp(1.0f, e); }
+        expo[a] = (uint8_t)(e + 127);
+        for (int k = 0; k < 4; ++k) {
+            if (k >= n.nk) { qmins[a][k] = 255; qmaxs[a][k] = 0; continue; }
+            int q0 = (int)std::floor((mins[a][k] - lo) / scale), q1 = (int)std::ceil((maxs[a][k] - lo) / scale);
+            q0 = std::max(0, std::min(255, q0)); q1 = std::max(0, std::min(255, q1));
+            while (q0 > 0 && decodePlane((uint8_t)q0, scale, lo) > mins[a][k]) --q0;
+            while (q1 < 255 && decodePlane((uint8_t)q1, scale, lo) < maxs[a][k]) ++q1;
+            qmins[a][k] = (uint8_t)q0; qmaxs[a][k] = (uint8_t)q1;
+        }
+    }
+    out.ox = origin[0]; out.oy = origin[1]; out.oz = origin[2];
+    out.ex = expo[0]; out.ey = expo[1]; out.ez = expo[2]; out.epad = 0;
+    for (int k = 0; k < 4; ++k) out.child[k] = k < n.nk ? n.child[k] : 0u;
+}
 
 bool BVH4::build(const float *positions, const uint32_t *indices, uint64_t nTris, const uint32_t *shapeOfPrim, std::string &err) {
     nodes.clear(); tris.clear(); info = Info();
@@ -197,27 +236,29 @@ bool BVH4::build(const float *positions, const uint32_t *indices, uint64_t nTris
     b.freeThreads = (int)std::min(16u, hw ? hw : 1u) - 1;
     const uint32_t root = b.build(0, (uint32_t)nTris, 0);
     tris.reserve(nTris);
-    nodes.reserve(nTris / 2 + 16);
-    Collapser c{ b, positions, indices, shapeOfPrim, nodes, tris, info };
+    std::vector<Node4F> wide;
+    wide.reserve(nTris / 2 + 16);
+    Collapser c{ b, positions, indices, shapeOfPrim, wide, tris, info };
     const Node2 &r = b.nodes[root];
     for (int a = 0; a < 3; ++a) { info.bmin[a] = r.box.mn[a]; info.bmax[a] = r.box.mx[a]; }
     if (r.count > 0) {
         /* single-leaf scene: wrap it in a root node */
-        Node4 nd;
+        Node4F nd; nd.nk = 1;
         for (int k = 0; k < 4; ++k) {
-            /* empty slot: min = max = +inf makes every slab interval empty for any ray direction */
             nd.minx[k] = nd.miny[k] = nd.minz[k] = INFINITY; nd.maxx[k] = nd.maxy[k] = nd.maxz[k] = INFINITY;
-            nd.child[k] = 0; nd.pad[k] = 0;
+            nd.child[k] = 0;
         }
         nd.minx[0] = r.box.mn[0]; nd.miny[0] = r.box.mn[1]; nd.minz[0] = r.box.mn[2];
         nd.maxx[0] = r.box.mx[0]; nd.maxy[0] = r.box.mx[1]; nd.maxz[0] = r.box.mx[2];
-        nodes.emplace_back();
+        wide.emplace_back();
         nd.child[0] = c.emitLeaf(r);
-        nodes[0] = nd;
+        wide[0] = nd;
         info.maxDepth = 1; info.maxStack = 0;
     } else {
         c.emit(root, 0, 0);
     }
+    nodes.resize(wide.size());
+    for (size_t i = 0; i < wide.size(); ++i) quantizeNode(wide[i], nodes[i]);
     info.nNodes = nodes.size(); info.nLeafTris = tris.size();
     return true;
 }

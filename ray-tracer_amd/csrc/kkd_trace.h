@@ -7,7 +7,7 @@
  * TriAccel projection test).  Kept from the reference: the adaptive epsilon rule, the [mint, maxt]
  * acceptance interval, the hit record (t, barycentrics of vertices 1 and 2, primitive).
  *
- * Memory shape: a node visit is eight 16-byte loads of one 128-byte line (Node4), a triangle test is
+ * Memory shape: a node visit is four 16-byte loads of one 64-byte record (Node4, 8-bit child boxes), a triangle test is
  * three 16-byte loads (LeafTri); the first STACK entries of a lane's stack live in LDS (index = slot * BLOCK +
  * thread, so the two 32-lane halves of a wave never collide on a bank) and only deeper entries, which the SAH
  * trees of the configs almost never reach, spill to a per-lane private array of kStackOverflow words.
@@ -102,7 +102,7 @@ __device__ __forceinline__ DHit traverse(const Node4 *__restrict__ nodes, const 
     const float idy = fabsf(ray.dy) < kTiny ? copysignf(kBig, ray.dy) : 1.0f / ray.dy;
     const float idz = fabsf(ray.dz) < kTiny ? copysignf(kBig, ray.dz) : 1.0f / ray.dz;
     WoopRay wr; wr.init(ray.dx, ray.dy, ray.dz);
-    const float4 *nodes4 = reinterpret_cast<const float4 *>(nodes);
+    const uint4 *nodes4 = reinterpret_cast<const uint4 *>(nodes);
     const float4 *tris4 = reinterpret_cast<const float4 *>(tris);
     const int tid = threadIdx.x;
     uint32_t ovf[kStackOverflow];
@@ -113,21 +113,27 @@ __device__ __forceinline__ DHit traverse(const Node4 *__restrict__ nodes, const 
     for (int guard = 1 << 24; guard > 0; --guard) {
         if (!(cur & kLeafBit)) {
             if (COUNT) ++nNodes;
-            const float4 *n = nodes4 + (size_t)cur * 8;
-            const float4 mnx = n[0], mny = n[1], mnz = n[2], mxx = n[3], mxy = n[4], mxz = n[5];
-            const uint4 ch = *reinterpret_cast<const uint4 *>(n + 6);
+            const uint4 *n = nodes4 + (size_t)cur * 4;
+            const uint4 hd = n[0], ch = n[1], qa = n[2], qb = n[3];
+            const float gx = __uint_as_float(hd.x), gy = __uint_as_float(hd.y), gz = __uint_as_float(hd.z);
+            const float sx = __uint_as_float((hd.w & 0xffu) << 23), sy = __uint_as_float(((hd.w >> 8) & 0xffu) << 23),
+                        sz = __uint_as_float(((hd.w >> 16) & 0xffu) << 23);
             float d0, d1, d2, d3;
-#define KKD_SLAB(D, LX, LY, LZ, HX, HY, HZ) { \
-            const float tx0 = (LX - ox) * idx, tx1 = (HX - ox) * idx; \
-            const float ty0 = (LY - oy) * idy, ty1 = (HY - oy) * idy; \
-            const float tz0 = (LZ - oz) * idz, tz1 = (HZ - oz) * idz; \
+            /* plane = fmaf(q, scale, origin): the builder verified this exact expression encloses the child box */
+#define KKD_SLAB(D, K, C) { \
+            const float lx = fmaf((float)((qa.x >> (8 * K)) & 0xffu), sx, gx), hx = fmaf((float)((qa.w >> (8 * K)) & 0xffu), sx, gx); \
+            const float ly = fmaf((float)((qa.y >> (8 * K)) & 0xffu), sy, gy), hy = fmaf((float)((qb.x >> (8 * K)) & 0xffu), sy, gy); \
+            const float lz = fmaf((float)((qa.z >> (8 * K)) & 0xffu), sz, gz), hz = fmaf((float)((qb.y >> (8 * K)) & 0xffu), sz, gz); \
+            const float tx0 = (lx - ox) * idx, tx1 = (hx - ox) * idx; \
+            const float ty0 = (ly - oy) * idy, ty1 = (hy - oy) * idy; \
+            const float tz0 = (lz - oz) * idz, tz1 = (hz - oz) * idz; \
             const float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin)); \
             const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tmax)) * 1.0000004f; \
-            D = (tn <= tf) ? tn : kInf; }
-            KKD_SLAB(d0, mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x)
-            KKD_SLAB(d1, mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y)
-            KKD_SLAB(d2, mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z)
-            KKD_SLAB(d3, mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w)
+            D = (tn <= tf && (C) != 0u) ? tn : kInf; }
+            KKD_SLAB(d0, 0, ch.x)
+            KKD_SLAB(d1, 1, ch.y)
+            KKD_SLAB(d2, 2, ch.z)
+            KKD_SLAB(d3, 3, ch.w)
 #undef KKD_SLAB
             uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
 #define KKD_CSWAP(DA, CA, DB, CB) { const bool s = DB < DA; const float td = s ? DB : DA; DB = s ? DA : DB; DA = td; \

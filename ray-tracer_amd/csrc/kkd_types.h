@@ -17,15 +17,19 @@
 namespace kkd {
 
 /* ---- acceleration structure -------------------------------------------------------------------
- * 4-wide BVH, one 128-byte node = one L2 line: child boxes in SoA so a lane tests the four boxes
- * with eight 16-byte loads.  child[i]: bit31 set = leaf, bits 28..30 = triangle count - 1,
- * bits 0..27 = first LeafTri slot; otherwise index of the child node.  Unused children have
- * min = max = +inf and child = 0 -- no ray can enter them. */
-struct alignas(128) Node4 {
-    float minx[4], miny[4], minz[4];
-    float maxx[4], maxy[4], maxz[4];
+ * 4-wide BVH, one 64-byte node = half an L2 line = four 16-byte loads per lane.  What limits incoherent traversal on
+ * CDNA4 is the number of divergent 16-byte load instructions a wave issues (every lane touches its own line), not
+ * ALU work, so the four child boxes are stored as 8-bit grid coordinates relative to the node's own box:
+ *     plane = origin + q * 2^(exp - 127)      (exact power-of-two scale per axis)
+ * The builder rounds min planes down and max planes up and verifies the float decode (same fmaf) encloses the true
+ * box.  child[i]: 0 = empty slot (the root is never a child); bit31 set = leaf, bits 28..30 = triangle count - 1,
+ * bits 0..27 = first LeafTri slot; otherwise index of the child node. */
+struct alignas(64) Node4 {
+    float ox, oy, oz;            /* grid origin = min corner of the node box                    */
+    uint8_t ex, ey, ez, epad;    /* biased exponents of the per-axis grid scale                 */
     uint32_t child[4];
-    uint32_t pad[4];
+    uint8_t qminx[4], qminy[4], qminz[4], qmaxx[4];
+    uint8_t qmaxy[4], qmaxz[4]; uint32_t pad[2];
 };
 static constexpr uint32_t kLeafBit = 0x80000000u;
 static constexpr uint32_t kLeafStartMask = 0x0FFFFFFFu;
