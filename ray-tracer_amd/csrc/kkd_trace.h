@@ -101,6 +101,7 @@ __device__ __forceinline__ DHit traverse(const Node4 *__restrict__ nodes, const 
     const float idx = fabsf(ray.dx) < kTiny ? copysignf(kBig, ray.dx) : 1.0f / ray.dx;
     const float idy = fabsf(ray.dy) < kTiny ? copysignf(kBig, ray.dy) : 1.0f / ray.dy;
     const float idz = fabsf(ray.dz) < kTiny ? copysignf(kBig, ray.dz) : 1.0f / ray.dz;
+    const bool negx = idx < 0.f, negy = idy < 0.f, negz = idz < 0.f;
     WoopRay wr; wr.init(ray.dx, ray.dy, ray.dz);
     const uint4 *nodes4 = reinterpret_cast<const uint4 *>(nodes);
     const float4 *tris4 = reinterpret_cast<const float4 *>(tris);
@@ -119,17 +120,22 @@ __device__ __forceinline__ DHit traverse(const Node4 *__restrict__ nodes, const 
             const float sx = __uint_as_float((hd.w & 0xffu) << 23), sy = __uint_as_float(((hd.w >> 8) & 0xffu) << 23),
                         sz = __uint_as_float(((hd.w >> 16) & 0xffu) << 23);
             float d0, d1, d2, d3;
-            /* plane = fmaf(q, scale, origin): the builder verified this exact expression encloses the child box */
+            /* Slab test in the node's grid: t(plane q) = (origin + q * scale - o) / d = q * ta + tb, so a plane costs one
+             * byte->float conversion and one fma.  The near / far plane of each axis is picked by the sign of the ray
+             * direction for all four children at once (one select of the packed byte quadruple).  The 1e-6 slack on
+             * both sides covers the rounding of ta, tb (the builder's enclosure check covers the grid itself). */
+            const float tax = sx * idx, tay = sy * idy, taz = sz * idz;
+            const float tbx = (gx - ox) * idx, tby = (gy - oy) * idy, tbz = (gz - oz) * idz;
+            const uint32_t nx4 = negx ? qa.w : qa.x, fx4 = negx ? qa.x : qa.w;
+            const uint32_t ny4 = negy ? qb.x : qa.y, fy4 = negy ? qa.y : qb.x;
+            const uint32_t nz4 = negz ? qb.y : qa.z, fz4 = negz ? qa.z : qb.y;
 #define KKD_SLAB(D, K, C) { \
-            const float lx = fmaf((float)((qa.x >> (8 * K)) & 0xffu), sx, gx), hx = fmaf((float)((qa.w >> (8 * K)) & 0xffu), sx, gx); \
-            const float ly = fmaf((float)((qa.y >> (8 * K)) & 0xffu), sy, gy), hy = fmaf((float)((qb.x >> (8 * K)) & 0xffu), sy, gy); \
-            const float lz = fmaf((float)((qa.z >> (8 * K)) & 0xffu), sz, gz), hz = fmaf((float)((qb.y >> (8 * K)) & 0xffu), sz, gz); \
-            const float tx0 = (lx - ox) * idx, tx1 = (hx - ox) * idx; \
-            const float ty0 = (ly - oy) * idy, ty1 = (hy - oy) * idy; \
-            const float tz0 = (lz - oz) * idz, tz1 = (hz - oz) * idz; \
-            const float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin)); \
-            const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tmax)) * 1.0000004f; \
-            D = (tn <= tf && (C) != 0u) ? tn : kInf; }
+            const float tnx = fmaf((float)((nx4 >> (8 * K)) & 0xffu), tax, tbx), tfx = fmaf((float)((fx4 >> (8 * K)) & 0xffu), tax, tbx); \
+            const float tny = fmaf((float)((ny4 >> (8 * K)) & 0xffu), tay, tby), tfy = fmaf((float)((fy4 >> (8 * K)) & 0xffu), tay, tby); \
+            const float tnz = fmaf((float)((nz4 >> (8 * K)) & 0xffu), taz, tbz), tfz = fmaf((float)((fz4 >> (8 * K)) & 0xffu), taz, tbz); \
+            const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin)); \
+            const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tmax)); \
+            D = (tn * 0.999999f <= tf * 1.000001f && (C) != 0u) ? tn : kInf; }
             KKD_SLAB(d0, 0, ch.x)
             KKD_SLAB(d1, 1, ch.y)
             KKD_SLAB(d2, 2, ch.z)
