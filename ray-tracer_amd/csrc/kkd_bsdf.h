@@ -190,8 +190,8 @@ __device__ __forceinline__ f3 ld3(const float *p) { return f3(p[0], p[1], p[2]);
 __device__ __forceinline__ f3 reflectLocal(f3 wi, f3 m) { return 2.f * dot(wi, m) * m - wi; }
 
 /* rtrans.h:183-191: Catmull-Rom lookup in cosTheta^(1/4), clamped to [0,1] */
-__device__ inline float roughTransEval(const float *tab, float cosTheta) {
-    float x = powf(fabsf(cosTheta), 0.25f);
+__device__ __forceinline__ float roughTransEval(const float *tab, float cosTheta) {
+    float x = sqrtf(sqrtf(fabsf(cosTheta)));   /* cosTheta^(1/4), rtrans.h:187 */
     if (!(x >= 0.f && x <= 1.f)) return 0.f;
     float t = x * 99.f;
     int k = max(0, min((int)t, 98));
@@ -203,13 +203,13 @@ __device__ inline float roughTransEval(const float *tab, float cosTheta) {
     float r = (2.f * t3 - 3.f * t2 + 1.f) * f0 + (-2.f * t3 + 3.f * t2) * f1 + (t3 - 2.f * t2 + t) * d0 + (t3 - t2) * d1;
     return fminf(1.0f, fmaxf(0.0f, r));
 }
-__device__ inline float plasticProbSpecular(const DMaterial &m, const float *tab, float cosThetaI) {
+__device__ __forceinline__ float plasticProbSpecular(const DMaterial &m, const float *tab, float cosThetaI) {
     float p = 1.f - roughTransEval(tab, cosThetaI);
     return (p * m.specSamplingWeight) / (p * m.specSamplingWeight + (1.f - p) * (1.f - m.specSamplingWeight));
 }
 
 /* eval / pdf of a non-twosided material (wi.z sign already resolved by the caller) */
-__device__ inline f3 bsdfEvalBase(const DMaterial &m, const float *rtTables, f3 wi, f3 wo) {
+__device__ __forceinline__ f3 bsdfEvalBase(const DMaterial &m, const float *rtTables, f3 wi, f3 wo) {
     switch (m.type) {
         case KKD_BSDF_DIFFUSE:
             if (!(m.typeFlags & EDiffuseReflection) || wi.z <= 0.f || wo.z <= 0.f) return f3(0.f);
@@ -240,7 +240,7 @@ __device__ inline f3 bsdfEvalBase(const DMaterial &m, const float *rtTables, f3 
         default: return f3(0.f);   /* dielectric: nothing in the solid-angle measure (dielectric.cpp:228-253) */
     }
 }
-__device__ inline float bsdfPdfBase(const DMaterial &m, const float *rtTables, f3 wi, f3 wo) {
+__device__ __forceinline__ float bsdfPdfBase(const DMaterial &m, const float *rtTables, f3 wi, f3 wo) {
     switch (m.type) {
         case KKD_BSDF_DIFFUSE:
             if (!(m.typeFlags & EDiffuseReflection) || wi.z <= 0.f || wo.z <= 0.f) return 0.f;
@@ -266,7 +266,7 @@ __device__ inline float bsdfPdfBase(const DMaterial &m, const float *rtTables, f
     }
 }
 /* returns the importance weight f*cos/pdf; sampledType gets the BSDF::EBSDFType bit of the lobe */
-__device__ inline f3 bsdfSampleBase(const DMaterial &m, const float *rtTables, f3 wi, f2 s, f3 &wo, float &pdfOut, uint32_t &sampledType) {
+__device__ __forceinline__ f3 bsdfSampleBase(const DMaterial &m, const float *rtTables, f3 wi, f2 s, f3 &wo, float &pdfOut, uint32_t &sampledType) {
     sampledType = 0; pdfOut = 0.f; wo = f3(0.f);
     switch (m.type) {
         case KKD_BSDF_DIFFUSE:
@@ -332,7 +332,7 @@ __device__ inline f3 bsdfSampleBase(const DMaterial &m, const float *rtTables, f
 }
 
 /* ---- dispatch through the twosided adapter (twosided.cpp:108-183) ---- */
-__device__ inline f3 evalBsdf(const DScene &sc, int id, f3 wi, f3 wo) {
+__device__ __forceinline__ f3 evalBsdf(const DScene &sc, int id, f3 wi, f3 wo) {
     const DMaterial *m = sc.materials + id;
     if (m->type == KKD_BSDF_TWOSIDED) {
         if (wi.z > 0.f) m = sc.materials + m->nested0;
@@ -340,7 +340,7 @@ __device__ inline f3 evalBsdf(const DScene &sc, int id, f3 wi, f3 wo) {
     }
     return bsdfEvalBase(*m, sc.rtTables, wi, wo);
 }
-__device__ inline float pdfBsdf(const DScene &sc, int id, f3 wi, f3 wo) {
+__device__ __forceinline__ float pdfBsdf(const DScene &sc, int id, f3 wi, f3 wo) {
     const DMaterial *m = sc.materials + id;
     if (m->type == KKD_BSDF_TWOSIDED) {
         if (wi.z > 0.f) m = sc.materials + m->nested0;
@@ -348,7 +348,7 @@ __device__ inline float pdfBsdf(const DScene &sc, int id, f3 wi, f3 wo) {
     }
     return bsdfPdfBase(*m, sc.rtTables, wi, wo);
 }
-__device__ inline f3 sampleBsdf(const DScene &sc, int id, f3 wi, f2 s, f3 &wo, float &pdfOut, uint32_t &sampledType) {
+__device__ __forceinline__ f3 sampleBsdf(const DScene &sc, int id, f3 wi, f2 s, f3 &wo, float &pdfOut, uint32_t &sampledType) {
     const DMaterial *m = sc.materials + id;
     bool flipped = false;
     if (m->type == KKD_BSDF_TWOSIDED) {

@@ -27,7 +27,7 @@ struct DirectRec { f3 ref, refN, p, n, d; float dist, pdf; int measure /* 0 soli
 __device__ __forceinline__ f3 ldv(const float *base, uint32_t i) { const float *p = base + 3 * (size_t)i; return f3(p[0], p[1], p[2]); }
 
 /* perspective.cpp:271-298 */
-__device__ inline DRay sensorRay(const DSensor &s, float px, float py) {
+__device__ __forceinline__ DRay sensorRay(const DSensor &s, float px, float py) {
     const float x = px * s.invResX, y = py * s.invResY;
     const float *m = s.s2c;
     float cx = m[0] * x + m[1] * y + m[3], cy = m[4] * x + m[5] * y + m[7], cz = m[8] * x + m[9] * y + m[11], cw = m[12] * x + m[13] * y + m[15];
@@ -47,7 +47,7 @@ __device__ inline DRay sensorRay(const DSensor &s, float px, float py) {
 /* Hit record from (slot, u, v).  full=false skips the shading frame tangents and wi (emitter lookups only
  * need p / shading normal). */
 template <bool FULL>
-__device__ inline void fillIntersection(const DScene &sc, f3 rayD, const DHit &hit, Its &its) {
+__device__ __forceinline__ void fillIntersection(const DScene &sc, f3 rayD, const DHit &hit, Its &its) {
     const float4 *tp = reinterpret_cast<const float4 *>(sc.tris) + (size_t)hit.id * 3;
     const float4 a = tp[0], b = tp[1], c = tp[2];
     const uint32_t prim = __float_as_uint(a.w), sh = __float_as_uint(b.w);
@@ -89,7 +89,7 @@ __device__ inline void fillIntersection(const DScene &sc, f3 rayD, const DHit &h
 }
 
 /* pmf.h DiscreteDistribution::sample: lower_bound over n+1 entries, skip zero-probability entries */
-__device__ inline uint32_t cdfSample(const float *cdf, uint32_t n, float v) {
+__device__ __forceinline__ uint32_t cdfSample(const float *cdf, uint32_t n, float v) {
     uint32_t lo = 0, cnt = n + 1;
     while (cnt > 0) {
         const uint32_t step = cnt >> 1, mid = lo + step;
@@ -100,7 +100,7 @@ __device__ inline uint32_t cdfSample(const float *cdf, uint32_t n, float v) {
     while (index + 1 < n && cdf[index + 1] - cdf[index] == 0.f) ++index;
     return index;
 }
-__device__ inline uint32_t cdfSampleReuse(const float *cdf, uint32_t n, float &v, float &pdf) {
+__device__ __forceinline__ uint32_t cdfSampleReuse(const float *cdf, uint32_t n, float &v, float &pdf) {
     const uint32_t index = cdfSample(cdf, n, v);
     const float c0 = cdf[index], c1 = cdf[index + 1];
     pdf = c1 - c0;
@@ -108,7 +108,7 @@ __device__ inline uint32_t cdfSampleReuse(const float *cdf, uint32_t n, float &v
     return index;
 }
 /* envmap.cpp:653-658 */
-__device__ inline uint32_t envSampleReuse(const float *cdf, uint32_t size, float &sample) {
+__device__ __forceinline__ uint32_t envSampleReuse(const float *cdf, uint32_t size, float &sample) {
     uint32_t lo = 0, cnt = size + 1;
     while (cnt > 0) {
         const uint32_t step = cnt >> 1, mid = lo + step;
@@ -124,7 +124,7 @@ __device__ __forceinline__ f3 rot3(const float *R, f3 v) {
     return f3(R[0] * v.x + R[1] * v.y + R[2] * v.z, R[3] * v.x + R[4] * v.y + R[5] * v.z, R[6] * v.x + R[7] * v.y + R[8] * v.z);
 }
 /* mipmap.h evalTexel: repeat in U, clamp in V (envmap.cpp:145-146); texels are stored as half */
-__device__ inline f3 envTexel(const DEnvMap &e, int x, int y) {
+__device__ __forceinline__ f3 envTexel(const DEnvMap &e, int x, int y) {
     x = x % e.w; if (x < 0) x += e.w;
     y = min(max(y, 0), e.h - 1);
     const uint2 raw = reinterpret_cast<const uint2 *>(e.texels)[(size_t)y * e.w + x];
@@ -132,14 +132,14 @@ __device__ inline f3 envTexel(const DEnvMap &e, int x, int y) {
     const float2 frg = __half22float2(rg), fba = __half22float2(ba);
     return f3(frg.x, frg.y, fba.x);
 }
-__device__ inline void envBilinearRows(const DEnvMap &e, float u, float v, f3 &value1, f3 &value2, int &yPos) {
+__device__ __forceinline__ void envBilinearRows(const DEnvMap &e, float u, float v, f3 &value1, f3 &value2, int &yPos) {
     const int xPos = (int)floorf(u); yPos = (int)floorf(v);
     const float dx1 = u - xPos, dx2 = 1.0f - dx1, dy1 = v - yPos, dy2 = 1.0f - dy1;
     value1 = envTexel(e, xPos, yPos) * dx2 * dy2 + envTexel(e, xPos + 1, yPos) * dx1 * dy2;
     value2 = envTexel(e, xPos, yPos + 1) * dx2 * dy1 + envTexel(e, xPos + 1, yPos + 1) * dx1 * dy1;
 }
 /* envmap.cpp:380-393,408-409 without ray differentials: bilinear level-0 lookup */
-__device__ inline f3 envEval(const DEnvMap &e, f3 worldDir) {
+__device__ __forceinline__ f3 envEval(const DEnvMap &e, f3 worldDir) {
     const f3 v = rot3(e.toLocal, worldDir);
     const float uu = atan2f(v.x, -v.z) * kInvTwoPi, vv = safeAcos(v.y) * kInvPi;
     if (!isfinite(uu) || !isfinite(vv)) return f3(0.f);
@@ -148,7 +148,7 @@ __device__ inline f3 envEval(const DEnvMap &e, f3 worldDir) {
     return (a + b) * e.scale;
 }
 /* envmap.cpp:603-633 */
-__device__ inline float envPdfDirection(const DEnvMap &e, f3 d) {
+__device__ __forceinline__ float envPdfDirection(const DEnvMap &e, f3 d) {
     const float uu = atan2f(d.x, -d.z) * kInvTwoPi, vv = safeAcos(d.y) * kInvPi;
     if (!isfinite(uu) || !isfinite(vv)) return 0.f;
     f3 a, b; int yPos;
@@ -158,7 +158,7 @@ __device__ inline float envPdfDirection(const DEnvMap &e, f3 d) {
            * e.normalization / fmaxf(fabsf(sinTheta), kEpsilon);
 }
 /* envmap.cpp:567-600 */
-__device__ inline void envSampleDirection(const DEnvMap &e, f2 sample, f3 &d, f3 &value, float &pdf) {
+__device__ __forceinline__ void envSampleDirection(const DEnvMap &e, f2 sample, f3 &d, f3 &value, float &pdf) {
     const uint32_t row = envSampleReuse(e.cdfRows, (uint32_t)e.h, sample.y);
     const uint32_t col = envSampleReuse(e.cdfCols + (size_t)row * (e.w + 1), (uint32_t)e.w, sample.x);
     const float px = (float)col + intervalToTent(sample.x), py = (float)row + intervalToTent(sample.y);
@@ -181,7 +181,7 @@ __device__ __forceinline__ f3 areaEval(const DEmitter &e, f3 shN, f3 d) {
 
 /* Scene::sampleEmitterDirect WITHOUT the visibility test (the shadow ray is queued by the caller):
  * returns value = Le / pdf with pdf including the emitter-selection probability; zero if not sampleable. */
-__device__ inline f3 sampleEmitterDirectUnoccluded(const DScene &sc, DirectRec &dRec, f2 sample) {
+__device__ __forceinline__ f3 sampleEmitterDirectUnoccluded(const DScene &sc, DirectRec &dRec, f2 sample) {
     float emPdf;
     const uint32_t index = cdfSampleReuse(sc.emitterCdf, sc.nEmitters, sample.x, emPdf);
     const DEmitter e = sc.emitters[index];
@@ -243,7 +243,7 @@ __device__ inline f3 sampleEmitterDirectUnoccluded(const DScene &sc, DirectRec &
 }
 
 /* scene.cpp:949-952 */
-__device__ inline float pdfEmitterDirect(const DScene &sc, const DirectRec &dRec) {
+__device__ __forceinline__ float pdfEmitterDirect(const DScene &sc, const DirectRec &dRec) {
     const DEmitter e = sc.emitters[dRec.emitter];
     float pdf = 0.f;
     if (e.type == KKD_EMITTER_AREA) {
