@@ -72,7 +72,7 @@ __device__ __forceinline__ void countTraversal(uint32_t nn, uint32_t nt, DeviceC
 }
 
 template <bool COUNT, int STACK, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) kPrimary(DScene sc, BatchParams bp, DHit *__restrict__ hits, DeviceCounters *ctr) {
+__global__ void __launch_bounds__(BLOCK, 8) kPrimary(DScene sc, BatchParams bp, DHit *__restrict__ hits, DeviceCounters *ctr) {
     __shared__ uint32_t sstack[STACK * BLOCK];
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     const SampleId s = mapWorkItem(bp, i);
@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(BLOCK) kPrimary(DScene sc, BatchParams bp, DHi
 /* ---- generic ray-buffer traversal ------------------------------------------------------------------ */
 /* OUT: 0 = DHit with LeafTri slot (internal), 1 = DHit with global primitive id (C ABI), 2 = occlusion word */
 template <bool ANY, bool COUNT, int OUT, int STACK, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) kTrace(const Node4 *__restrict__ nodes, const LeafTri *__restrict__ tris,
+__global__ void __launch_bounds__(BLOCK, 8) kTrace(const Node4 *__restrict__ nodes, const LeafTri *__restrict__ tris,
                                                 const DRay *__restrict__ rays, uint64_t n, void *__restrict__ out, DeviceCounters *ctr, int cls) {
     __shared__ uint32_t sstack[STACK * BLOCK];
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;

@@ -94,7 +94,6 @@ __device__ __forceinline__ DHit traverse(const Node4 *__restrict__ nodes, const 
     const float ox = ray.ox, oy = ray.oy, oz = ray.oz;
     const float tmin = adaptiveMinT<ANY>(ray.mint, ox, oy, oz);
     float tmax = ray.maxt;
-    if (!(tmax > tmin)) return hit;
     /* A zero direction component would give 1/d = inf and 0 * inf = NaN for an origin lying exactly on a slab plane
      * (rays aimed along an axis at mesh vertices do that); a huge finite reciprocal keeps such a slab "inside". */
     const float kBig = 0x1p100f, kTiny = 0x1p-100f;
@@ -109,10 +108,24 @@ __device__ __forceinline__ DHit traverse(const Node4 *__restrict__ nodes, const 
     uint32_t ovf[kStackOverflow];
     int sp = 0;
 #define KKD_PUSH(V) { if (sp < STACK) sstack[sp * BLOCK + tid] = (V); else ovf[sp - STACK] = (V); ++sp; }
-    uint32_t cur = 0;   /* root */
-    /* every wave leaves this loop: the walk is finite on a tree, and the step bound ends it on a malformed one */
+/* the LDS read is unconditional and the private read a separate, rarely taken branch: one select between the two
+ * pointers would turn every pop into a flat load, which goes the long way round through the texture addresser */
+#define KKD_POP() { if (sp == 0) cur = kTraversalDone; else { --sp; cur = sstack[(sp < STACK ? sp : STACK - 1) * BLOCK + tid]; \
+                    if (sp >= STACK) cur = ovf[sp - STACK]; } }
+    /* cur: inner node index | leaf reference (kLeafBit) | kTraversalDone */
+    uint32_t cur = (tmax > tmin) ? 0u : kTraversalDone;
+    /* One step per iteration and lane: a node visit or ONE triangle test, so a lane at a leaf and a lane at a node both
+     * make progress and the iteration costs one node visit plus one triangle test, not the longest leaf of the wave.
+     * (Measured and rejected: parking lanes at leaves until N of them can be tested together -- fewer load instructions,
+     * more iterations, 4-20% slower for N = 8..48; and refilling idle lanes from a per-wave ray queue -- 84 VGPRs, slower.)
+     * Every wave leaves this loop: the walk is finite on a tree, and the step bound ends it on a malformed one. */
     for (int guard = 1 << 24; guard > 0; --guard) {
-        if (!(cur & kLeafBit)) {
+        const bool atNode = !(cur & kLeafBit);
+        const bool atLeaf = !atNode && cur != kTraversalDone;
+        const unsigned long long leafLanes = __ballot(atLeaf);
+        const bool anyNode = __ballot(atNode) != 0ull;
+        if (!anyNode && leafLanes == 0ull) break;
+        if (atNode) {
             if (COUNT) ++nNodes;
             const uint4 *n = nodes4 + (size_t)cur * 4;
             const uint4 hd = n[0], ch = n[1], qa = n[2], qb = n[3];
@@ -151,26 +164,28 @@ __device__ __forceinline__ DHit traverse(const Node4 *__restrict__ nodes, const 
                 if (d2 < kInf) KKD_PUSH(c2)
                 if (d1 < kInf) KKD_PUSH(c1)
                 cur = c0;
-                continue;
-            }
-        } else {
-            const uint32_t start = cur & kLeafStartMask, cnt = ((cur >> 28) & 7u) + 1u;
-            for (uint32_t i = 0; i < cnt; ++i) {
+            } else KKD_POP()
+        }
+        {
+            if (atLeaf) {
+                const uint32_t slot = cur & kLeafStartMask;
                 if (COUNT) ++nTris;
-                const float4 *tp = tris4 + (size_t)(start + i) * 3;
+                const float4 *tp = tris4 + (size_t)slot * 3;
                 const float4 a = tp[0], b = tp[1], c = tp[2];
                 float t, u, v;
+                bool done = false;
                 if (woopIntersect(wr, ox, oy, oz, a, b, c, tmin, tmax, t, u, v)) {
-                    tmax = t; hit.t = t; hit.u = u; hit.v = v; hit.id = start + i;
-                    if (ANY) return hit;
+                    tmax = t; hit.t = t; hit.u = u; hit.v = v; hit.id = slot;
+                    done = ANY;
                 }
+                if (done) cur = kTraversalDone;
+                else if (cur & (7u << 28)) cur = cur - (1u << 28) + 1u;   /* next triangle of this leaf */
+                else KKD_POP()
             }
         }
-        if (sp == 0) break;
-        --sp;
-        cur = sp < STACK ? sstack[sp * BLOCK + tid] : ovf[sp - STACK];
     }
 #undef KKD_PUSH
+#undef KKD_POP
     return hit;
 }
 

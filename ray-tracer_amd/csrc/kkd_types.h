@@ -33,6 +33,7 @@ struct alignas(64) Node4 {
 };
 static constexpr uint32_t kLeafBit = 0x80000000u;
 static constexpr uint32_t kLeafStartMask = 0x0FFFFFFFu;
+static constexpr uint32_t kTraversalDone = 0xFFFFFFFFu;   /* never a leaf reference: LeafTri slots stay below kLeafStartMask */
 static constexpr int kMaxLeafTris = 4;
 
 /* Triangles in leaf order, 48 bytes: three 16-byte loads.  w components carry ids (bit patterns). */
