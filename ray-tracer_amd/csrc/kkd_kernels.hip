@@ -120,7 +120,7 @@ __device__ __forceinline__ void storeRay(DRay *dst, const DRay &r) {
     p[0] = make_float4(r.ox, r.oy, r.oz, r.mint); p[1] = make_float4(r.dx, r.dy, r.dz, r.maxt);
 }
 
-__global__ void __launch_bounds__(256) kShade(DScene sc, BatchParams bp, WaveBuffers wb) {
+__global__ void __launch_bounds__(256, 4) kShade(DScene sc, BatchParams bp, WaveBuffers wb) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= bp.count) return;
     const SampleId s = mapWorkItem(bp, i);
