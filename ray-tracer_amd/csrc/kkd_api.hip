@@ -131,6 +131,7 @@ int kkd_scene_upload(kkd_ctx *ctx, const kkd_scene_desc *sd) {
     HostScene &hs = ctx->hs;
     /* the kernels index their stack without a bound check: the builder's worst-case occupancy must fit */
     if (hs.bvh.info.maxStack > kMaxTraversalStack) return fail(ctx, KKD_ERR_UNSUPPORTED, "acceleration structure deeper than the traversal stack");
+    for (LeafTri &t : hs.bvh.tris) { const int32_t e = hs.shapes[t.shape].emitter; t.emitter = e >= 0 ? (uint32_t)e + 1u : 0u; }
     KKD_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
 #define UP(buf, ptr, n) if ((rc = upload(ctx, ctx->buf, ptr, n)) != KKD_OK) return rc;

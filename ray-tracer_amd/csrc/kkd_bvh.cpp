@@ -130,7 +130,7 @@ struct Collapser {
             LeafTri t;
             t.v0x = a[0]; t.v0y = a[1]; t.v0z = a[2]; t.prim = p;
             t.v1x = bb[0]; t.v1y = bb[1]; t.v1z = bb[2]; t.shape = shapeOfPrim[p];
-            t.v2x = c[0]; t.v2y = c[1]; t.v2z = c[2]; t.pad = 0;
+            t.v2x = c[0]; t.v2y = c[1]; t.v2z = c[2]; t.emitter = 0;
             tris.push_back(t);
         }
         return kLeafBit | ((n.count - 1) << 28) | start;

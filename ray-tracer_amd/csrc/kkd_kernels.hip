@@ -102,6 +102,7 @@ __global__ void __launch_bounds__(BLOCK, 8) kTrace(const Node4 *__restrict__ nod
         if (OUT == 2) reinterpret_cast<uint32_t *>(out)[i] = h.id != kNoHit ? 1u : 0u;
         else {
             if (OUT == 1 && h.id != kNoHit) h.id = tris[h.id].prim;
+            if (OUT == 0 && h.id != kNoHit && tris[h.id].emitter == 0u) h.id |= kHitNotEmitter;
             reinterpret_cast<DHit *>(out)[i] = h;
         }
     }
@@ -280,13 +281,15 @@ __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveB
         sx = (float)s.X + jit.x; sy = (float)s.Y + jit.y;
         const float4 acc = wb.accum[i];
         f3 L(acc.x, acc.y, acc.z);
-        const float4 rn = wb.refN[i];
         const float cB = nB / (float)(nB + nL), cL = nL / (float)(nB + nL);
         for (uint32_t b = 0; b < nB; ++b) {                        /* kk/direct.cpp:105-123 + :167-171 */
             const float4 rec = wb.brec0[(size_t)b * bp.stride + i];
             if (rec.w == 0.f || (bp.debug & 2u)) continue;
+            DHit h = wb.bsdfHits[(size_t)b * bp.stride + i];
+            if (h.id != kNoHit && (h.id & kHitNotEmitter)) continue;   /* hit a surface that does not emit: Le = 0 */
+            if (h.id == kNoHit && sc.envEmitter < 0) continue;
             const DRay r = wb.bsdfRays[(size_t)b * bp.stride + i];
-            const DHit h = wb.bsdfHits[(size_t)b * bp.stride + i];
+            const float4 rn = wb.refN[i];
             const f3 rd(r.dx, r.dy, r.dz);
             DirectRec dRec; dRec.ref = f3(r.ox, r.oy, r.oz); dRec.refN = f3(rn.x, rn.y, rn.z);
             f3 value;

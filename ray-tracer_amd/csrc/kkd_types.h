@@ -40,8 +40,11 @@ static constexpr int kMaxLeafTris = 4;
 struct alignas(16) LeafTri {
     float v0x, v0y, v0z; uint32_t prim;   /* global primitive id = first_prim + primIndex          */
     float v1x, v1y, v1z; uint32_t shape;  /* shape index (ShapeKDTree::addShape order)              */
-    float v2x, v2y, v2z; uint32_t pad;
+    float v2x, v2y, v2z; uint32_t emitter; /* area emitter of the shape + 1, 0 = none (filled in at upload)  */
 };
+/* set in the hit id of a BSDF-ray hit (internal hit buffers only) when the surface hit does not emit: the resolve
+ * kernel then needs neither the triangle nor the ray */
+static constexpr uint32_t kHitNotEmitter = 0x40000000u;
 
 /* ---- BSDF::EBSDFType bits used on this path (names follow the reference's bsdf.h) ---- */
 enum : uint32_t {
