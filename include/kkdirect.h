@@ -159,6 +159,9 @@ typedef struct kkd_scene_desc {
 /* ---- context / render parameters ----------------------------------------------------- */
 
 #define KKD_FLAG_COUNT_TRAVERSAL 1u  /* count visited nodes / tested triangles in every traversal (measurement runs) */
+#define KKD_FLAG_PROJECTION_TEST 2u  /* leaf test with the reference's own arithmetic (TriAccel = Wald's projection test,
+                                        src/librender/skdtree.cpp:77-104, 294-300) instead of the watertight test: hit ids then
+                                        equal ShapeKDTree's except for equal-distance ties; not watertight on shared edges */
 
 typedef struct kkd_config {
     int32_t  device;           /* HIP device ordinal                                           */

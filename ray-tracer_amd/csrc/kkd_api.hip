@@ -47,7 +47,7 @@ struct kkd_ctx {
     HostScene hs;
     DScene ds{};
     /* scene buffers */
-    DevBuf nodes, tris, positions, normals, texcoords, indices, shapes, materials, emitters, emitterCdf, areaCdf, rtTables,
+    DevBuf nodes, tris, projTris, positions, normals, texcoords, indices, shapes, materials, emitters, emitterCdf, areaCdf, rtTables,
            envTexels, envCdfRows, envCdfCols, envRowWeights;
     /* work buffers */
     DevBuf hits, accum, refN, bsdfRays, bsdfHits, brec0, shadowRays, occluded, lrec, film, counters, apiRays, apiHits;
@@ -113,7 +113,7 @@ void kkd_destroy(kkd_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
-    DevBuf *all[] = { &ctx->nodes, &ctx->tris, &ctx->positions, &ctx->normals, &ctx->texcoords, &ctx->indices, &ctx->shapes, &ctx->materials,
+    DevBuf *all[] = { &ctx->nodes, &ctx->tris, &ctx->projTris, &ctx->positions, &ctx->normals, &ctx->texcoords, &ctx->indices, &ctx->shapes, &ctx->materials,
                       &ctx->emitters, &ctx->emitterCdf, &ctx->areaCdf, &ctx->rtTables, &ctx->envTexels, &ctx->envCdfRows, &ctx->envCdfCols,
                       &ctx->envRowWeights, &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->shadowRays,
                       &ctx->occluded, &ctx->lrec, &ctx->film, &ctx->counters, &ctx->apiRays, &ctx->apiHits };
@@ -137,6 +137,10 @@ int kkd_scene_upload(kkd_ctx *ctx, const kkd_scene_desc *sd) {
 #define UP(buf, ptr, n) if ((rc = upload(ctx, ctx->buf, ptr, n)) != KKD_OK) return rc;
     UP(nodes, hs.bvh.nodes.data(), hs.bvh.nodes.size())
     UP(tris, hs.bvh.tris.data(), hs.bvh.tris.size())
+    if (ctx->cfg.flags & KKD_FLAG_PROJECTION_TEST) {
+        std::vector<ProjTri> pt; makeProjTris(hs.bvh.tris, pt);
+        UP(projTris, pt.data(), pt.size())
+    }
     UP(positions, sd->positions, 3 * (size_t)sd->n_verts)
     UP(normals, sd->normals, sd->normals ? 3 * (size_t)sd->n_verts : 0)
     UP(texcoords, sd->texcoords, sd->texcoords ? 2 * (size_t)sd->n_verts : 0)
@@ -156,6 +160,7 @@ int kkd_scene_upload(kkd_ctx *ctx, const kkd_scene_desc *sd) {
     DScene &d = ctx->ds;
     std::memset(&d, 0, sizeof(d));
     d.nodes = (const Node4 *)ctx->nodes.p; d.tris = (const LeafTri *)ctx->tris.p;
+    d.projTris = (ctx->cfg.flags & KKD_FLAG_PROJECTION_TEST) ? (const ProjTri *)ctx->projTris.p : nullptr;
     d.positions = (const float *)ctx->positions.p; d.normals = (const float *)ctx->normals.p; d.texcoords = (const float *)ctx->texcoords.p;
     d.indices = (const uint32_t *)ctx->indices.p;
     d.shapes = (const DShape *)ctx->shapes.p; d.materials = (const DMaterial *)ctx->materials.p; d.emitters = (const DEmitter *)ctx->emitters.p;

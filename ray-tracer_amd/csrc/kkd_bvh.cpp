@@ -263,4 +263,31 @@ bool BVH4::build(const float *positions, const uint32_t *indices, uint64_t nTris
     return true;
 }
 
+/* TriAccel::load of the reference (include/mitsuba/render/triaccel.h, used at skdtree.cpp:77-104): Wald's
+ * precomputed projection record.  Single precision, no contraction, the operation order of the published code, so that
+ * the device test reproduces the reference's hit / miss decisions and (t, u, v) bit for bit. */
+void makeProjTris(const std::vector<LeafTri> &tris, std::vector<ProjTri> &out) {
+    static const int waldModulo[4] = { 1, 2, 0, 1 };
+    out.resize(tris.size());
+    for (size_t i = 0; i < tris.size(); ++i) {
+        const LeafTri &t = tris[i];
+        ProjTri r; std::memset(&r, 0, sizeof(r));
+        const volatile float A[3] = { t.v0x, t.v0y, t.v0z };
+        const float b[3] = { t.v2x - t.v0x, t.v2y - t.v0y, t.v2z - t.v0z };   /* C - A */
+        const float c[3] = { t.v1x - t.v0x, t.v1y - t.v0y, t.v1z - t.v0z };   /* B - A */
+        const float N[3] = { c[1] * b[2] - c[2] * b[1], c[2] * b[0] - c[0] * b[2], c[0] * b[1] - c[1] * b[0] };
+        uint32_t k = 0;
+        for (int j = 0; j < 3; ++j) if (std::fabs(N[j]) > std::fabs(N[k])) k = (uint32_t)j;
+        const int u = waldModulo[k], v = waldModulo[k + 1];
+        const float n_k = N[k], denom = b[u] * c[v] - b[v] * c[u];
+        if (denom == 0.f) { r.k = 3; out[i] = r; continue; }
+        r.k = k;
+        r.n_u = N[u] / n_k; r.n_v = N[v] / n_k; r.n_d = (A[0] * N[0] + A[1] * N[1] + A[2] * N[2]) / n_k;
+        r.b_nu = b[u] / denom; r.b_nv = -b[v] / denom;
+        r.a_u = A[u]; r.a_v = A[v];
+        r.c_nu = c[v] / denom; r.c_nv = -c[u] / denom;
+        out[i] = r;
+    }
+}
+
 } /* namespace kkd */

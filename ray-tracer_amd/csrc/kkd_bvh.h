@@ -20,4 +20,6 @@ struct BVH4 {
     bool build(const float *positions, const uint32_t *indices, uint64_t nTris, const uint32_t *shapeOfPrim, std::string &err);
 };
 
+void makeProjTris(const std::vector<LeafTri> &tris, std::vector<ProjTri> &out);
+
 } /* namespace kkd */

@@ -71,7 +71,7 @@ __device__ __forceinline__ void countTraversal(uint32_t nn, uint32_t nt, DeviceC
     if ((threadIdx.x & 63) == 0) { atomicAdd(&ctr->nodes[cls], (unsigned long long)nn); atomicAdd(&ctr->tris[cls], (unsigned long long)nt); }
 }
 
-template <bool COUNT, int STACK, int BLOCK>
+template <bool COUNT, bool PROJ, int STACK, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, 8) kPrimary(DScene sc, BatchParams bp, DHit *__restrict__ hits, DeviceCounters *ctr) {
     __shared__ uint32_t sstack[STACK * BLOCK];
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(BLOCK, 8) kPrimary(DScene sc, BatchParams bp, 
     float sx, sy;
     if (s.active) ray = primaryRay(sc, bp, s, sx, sy);
     uint32_t nn = 0, nt = 0;
-    const DHit h = traverse<false, COUNT, STACK, BLOCK>(sc.nodes, sc.tris, ray, sstack, nn, nt);
+    const DHit h = traverse<false, COUNT, PROJ, STACK, BLOCK>(sc.nodes, PROJ ? (const void *)sc.projTris : (const void *)sc.tris, ray, sstack, nn, nt);
     if (i < bp.count) hits[i] = h;
     ctr = counterShard(ctr);
     countRays(s.active, &ctr->rays[KKD_RAYS_PRIMARY]);
@@ -89,15 +89,15 @@ __global__ void __launch_bounds__(BLOCK, 8) kPrimary(DScene sc, BatchParams bp, 
 
 /* ---- generic ray-buffer traversal ------------------------------------------------------------------ */
 /* OUT: 0 = DHit with LeafTri slot (internal), 1 = DHit with global primitive id (C ABI), 2 = occlusion word */
-template <bool ANY, bool COUNT, int OUT, int STACK, int BLOCK>
-__global__ void __launch_bounds__(BLOCK, 8) kTrace(const Node4 *__restrict__ nodes, const LeafTri *__restrict__ tris,
+template <bool ANY, bool COUNT, int OUT, bool PROJ, int STACK, int BLOCK>
+__global__ void __launch_bounds__(BLOCK, 8) kTrace(const Node4 *__restrict__ nodes, const LeafTri *__restrict__ tris, const ProjTri *__restrict__ projTris,
                                                 const DRay *__restrict__ rays, uint64_t n, void *__restrict__ out, DeviceCounters *ctr, int cls) {
     __shared__ uint32_t sstack[STACK * BLOCK];
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     DRay ray; ray.maxt = -1.f; ray.mint = 0.f; ray.ox = ray.oy = ray.oz = 0.f; ray.dx = ray.dy = 0.f; ray.dz = 1.f;
     if (i < n) ray = rays[i];
     uint32_t nn = 0, nt = 0;
-    DHit h = traverse<ANY, COUNT, STACK, BLOCK>(nodes, tris, ray, sstack, nn, nt);
+    DHit h = traverse<ANY, COUNT, PROJ, STACK, BLOCK>(nodes, PROJ ? (const void *)projTris : (const void *)tris, ray, sstack, nn, nt);
     if (i < n) {
         if (OUT == 2) reinterpret_cast<uint32_t *>(out)[i] = h.id != kNoHit ? 1u : 0u;
         else {
@@ -373,13 +373,20 @@ __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveB
 static inline uint32_t blocksFor(uint64_t n, uint32_t block) { return (uint32_t)((n + block - 1) / block); }
 
 void launchPrimary(hipStream_t st, bool count, const DScene &sc, const BatchParams &bp, DHit *hits, DeviceCounters *ctr) {
-    if (count) hipLaunchKernelGGL((kPrimary<true, kStackLds, 256>), dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, hits, ctr);
-    else hipLaunchKernelGGL((kPrimary<false, kStackLds, 256>), dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, hits, ctr);
+    const dim3 grid(blocksFor(bp.count, 256)), block(256);
+    if (sc.projTris) {
+        if (count) hipLaunchKernelGGL((kPrimary<true, true, kStackLds, 256>), grid, block, 0, st, sc, bp, hits, ctr);
+        else hipLaunchKernelGGL((kPrimary<false, true, kStackLds, 256>), grid, block, 0, st, sc, bp, hits, ctr);
+    } else {
+        if (count) hipLaunchKernelGGL((kPrimary<true, false, kStackLds, 256>), grid, block, 0, st, sc, bp, hits, ctr);
+        else hipLaunchKernelGGL((kPrimary<false, false, kStackLds, 256>), grid, block, 0, st, sc, bp, hits, ctr);
+    }
 }
 
 template <bool ANY, bool COUNT, int OUT>
 static void launchTraceT(hipStream_t st, const DScene &sc, const DRay *rays, uint64_t n, void *out, DeviceCounters *ctr, int cls) {
-    hipLaunchKernelGGL((kTrace<ANY, COUNT, OUT, kStackLds, 256>), dim3(blocksFor(n, 256)), dim3(256), 0, st, sc.nodes, sc.tris, rays, n, out, ctr, cls);
+    if (sc.projTris) hipLaunchKernelGGL((kTrace<ANY, COUNT, OUT, true, kStackLds, 256>), dim3(blocksFor(n, 256)), dim3(256), 0, st, sc.nodes, sc.tris, sc.projTris, rays, n, out, ctr, cls);
+    else hipLaunchKernelGGL((kTrace<ANY, COUNT, OUT, false, kStackLds, 256>), dim3(blocksFor(n, 256)), dim3(256), 0, st, sc.nodes, sc.tris, sc.projTris, rays, n, out, ctr, cls);
 }
 
 void launchTrace(hipStream_t st, const DScene &sc, const DRay *rays, uint64_t n, bool anyHit, bool count, int outMode, void *out, DeviceCounters *ctr, int cls) {

@@ -43,6 +43,7 @@ struct WoopRay {
 __device__ __forceinline__ bool woopIntersect(const WoopRay &w, float ox, float oy, float oz,
                                               const float4 &a, const float4 &b, const float4 &c,
                                               float tmin, float tmax, float &tOut, float &uOut, float &vOut) {
+#pragma clang fp contract(off)   /* __fmul_rn / __fsub_rn alone do not stop hipcc from fusing across them */
     const float Ax0 = a.x - ox, Ay0 = a.y - oy, Az0 = a.z - oz;
     const float Bx0 = b.x - ox, By0 = b.y - oy, Bz0 = b.z - oz;
     const float Cx0 = c.x - ox, Cy0 = c.y - oy, Cz0 = c.z - oz;
@@ -72,6 +73,30 @@ __device__ __forceinline__ bool woopIntersect(const WoopRay &w, float ox, float 
     return true;
 }
 
+/* KKD_FLAG_PROJECTION_TEST: TriAccel::rayIntersect of the reference (Wald's projection test; triaccel.h, called from the
+ * leaf loop skdtree.cpp:294-300 / gkdtree.h).  Same operations in the same order, each rounded on its own (no fma
+ * contraction, IEEE division), so a triangle is hit or missed, and gets the (t, u, v), exactly as on the CPU. */
+__device__ __forceinline__ bool projIntersect(float ox, float oy, float oz, float dx, float dy, float dz,
+                                              const float4 &r0, const float4 &r1, const float4 &r2,
+                                              float tmin, float tmax, float &tOut, float &uOut, float &vOut) {
+#pragma clang fp contract(off)   /* __fmul_rn / __fadd_rn alone do not stop hipcc from fusing across them */
+    const uint32_t k = __float_as_uint(r0.w);
+    if (k > 2u) return false;
+    const float o_u = k == 0u ? oy : (k == 1u ? oz : ox), o_v = k == 0u ? oz : (k == 1u ? ox : oy), o_k = k == 0u ? ox : (k == 1u ? oy : oz);
+    const float d_u = k == 0u ? dy : (k == 1u ? dz : dx), d_v = k == 0u ? dz : (k == 1u ? dx : dy), d_k = k == 0u ? dx : (k == 1u ? dy : dz);
+    const float n_u = r0.x, n_v = r0.y, n_d = r0.z, a_u = r1.x, a_v = r1.y, b_nu = r1.z, b_nv = r1.w, c_nu = r2.x, c_nv = r2.y;
+    const float num = __fsub_rn(__fsub_rn(__fsub_rn(n_d, __fmul_rn(o_u, n_u)), __fmul_rn(o_v, n_v)), o_k);
+    const float den = __fadd_rn(__fadd_rn(__fmul_rn(d_u, n_u), __fmul_rn(d_v, n_v)), d_k);
+    const float t = __fdiv_rn(num, den);
+    if (t < tmin || t > tmax) return false;
+    const float hu = __fsub_rn(__fadd_rn(o_u, __fmul_rn(t, d_u)), a_u), hv = __fsub_rn(__fadd_rn(o_v, __fmul_rn(t, d_v)), a_v);
+    const float u = __fadd_rn(__fmul_rn(hv, b_nu), __fmul_rn(hu, b_nv));
+    const float v = __fadd_rn(__fmul_rn(hu, c_nu), __fmul_rn(hv, c_nv));
+    if (!(u >= 0.f && v >= 0.f && __fadd_rn(u, v) <= 1.0f)) return false;
+    tOut = t; uOut = u; vOut = v;
+    return true;
+}
+
 /* adaptive ray epsilon, skdtree.cpp:126-129 (closest hit) and :213-214 (shadow rays: no inner clamp) */
 template <bool ANY> __device__ __forceinline__ float adaptiveMinT(float mint, float ox, float oy, float oz) {
     if (mint == kEpsilon) {
@@ -85,10 +110,11 @@ template <bool ANY> __device__ __forceinline__ float adaptiveMinT(float mint, fl
 /*
  * ANY      : stop at the first hit (ShapeKDTree::rayIntersect(ray)); else closest hit.
  * COUNT    : accumulate visited nodes / tested triangles (the N_nodes, N_tris of the roofline formula).
+ * PROJ     : tris is the ProjTri table and the leaf test is the reference's projection test; else LeafTri + watertight.
  * Returns hit.id = LeafTri slot or kNoHit.
  */
-template <bool ANY, bool COUNT, int STACK, int BLOCK>
-__device__ __forceinline__ DHit traverse(const Node4 *__restrict__ nodes, const LeafTri *__restrict__ tris,
+template <bool ANY, bool COUNT, bool PROJ, int STACK, int BLOCK>
+__device__ __forceinline__ DHit traverse(const Node4 *__restrict__ nodes, const void *__restrict__ tris,
                                          const DRay &ray, uint32_t *sstack, uint32_t &nNodes, uint32_t &nTris) {
     DHit hit; hit.t = kInf; hit.u = 0.f; hit.v = 0.f; hit.id = kNoHit;
     const float ox = ray.ox, oy = ray.oy, oz = ray.oz;
@@ -174,7 +200,8 @@ __device__ __forceinline__ DHit traverse(const Node4 *__restrict__ nodes, const 
                 const float4 a = tp[0], b = tp[1], c = tp[2];
                 float t, u, v;
                 bool done = false;
-                if (woopIntersect(wr, ox, oy, oz, a, b, c, tmin, tmax, t, u, v)) {
+                if (PROJ ? projIntersect(ox, oy, oz, ray.dx, ray.dy, ray.dz, a, b, c, tmin, tmax, t, u, v)
+                         : woopIntersect(wr, ox, oy, oz, a, b, c, tmin, tmax, t, u, v)) {
                     tmax = t; hit.t = t; hit.u = u; hit.v = v; hit.id = slot;
                     done = ANY;
                 }

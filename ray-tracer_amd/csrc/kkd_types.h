@@ -46,6 +46,14 @@ struct alignas(16) LeafTri {
  * kernel then needs neither the triangle nor the ray */
 static constexpr uint32_t kHitNotEmitter = 0x40000000u;
 
+/* Optional second triangle table for KKD_FLAG_PROJECTION_TEST: the reference's TriAccel record (Wald's projection
+ * test, skdtree.cpp:77-104 + triaccel.h), same slot order as LeafTri.  k = 3 marks a degenerate triangle. */
+struct alignas(16) ProjTri {
+    float n_u, n_v, n_d; uint32_t k;
+    float a_u, a_v, b_nu, b_nv;
+    float c_nu, c_nv; uint32_t pad[2];
+};
+
 /* ---- BSDF::EBSDFType bits used on this path (names follow the reference's bsdf.h) ---- */
 enum : uint32_t {
     EDiffuseReflection = 0x0004, EGlossyReflection = 0x0010, EDeltaReflection = 0x0040,
@@ -95,6 +103,7 @@ struct DFilter { float values[32]; float radius, scaleFactor; int32_t border, pa
 
 struct DScene {
     const Node4 *nodes; const LeafTri *tris;
+    const ProjTri *projTris;   /* non-null: leaf test with the reference's projection arithmetic */
     const float *positions; const float *normals; const float *texcoords; const uint32_t *indices;
     const DShape *shapes; const DMaterial *materials; const DEmitter *emitters;
     const float *emitterCdf;   /* nEmitters+1                                                 */

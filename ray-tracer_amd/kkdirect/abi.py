@@ -15,6 +15,7 @@ EMITTER_AREA, EMITTER_POINT, EMITTER_ENVMAP = range(3)
 RFILTER_GAUSSIAN, RFILTER_BOX, RFILTER_TENT, RFILTER_MITCHELL, RFILTER_CATMULLROM, RFILTER_LANCZOS = range(6)
 SHAPE_HAS_NORMALS, SHAPE_HAS_TEXCOORDS = 1, 2
 FLAG_COUNT_TRAVERSAL = 1
+FLAG_PROJECTION_TEST = 2
 RAYS_PRIMARY, RAYS_BSDF, RAYS_SHADOW = 0, 1, 2
 STAGE_NAMES = ("primary", "shade", "bsdf", "shadow", "resolve")
 

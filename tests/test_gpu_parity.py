@@ -101,6 +101,34 @@ def test_hit_ids_sponza_class_primary_and_secondary(gpu):
         assert info["node_bytes"] == 64 and info["tri_bytes"] == 48 and info["n_leaf_tris"] == sc._nt
 
 
+def test_hit_ids_projection_test_mode_bit_exact(gpu):
+    """KKD_FLAG_PROJECTION_TEST: the leaf test runs the reference's own TriAccel arithmetic, so the hit primitive AND
+    (t, u, v) must equal the oracle's ShapeKDTree restatement bit for bit; the only admissible differences are
+    documented ties, <= 1e-5 of the rays (the north-star bar) on the Cornell and the Sponza-class scene, for camera
+    rays, rays leaving surfaces and bounding-sphere chords, closest hit and any hit."""
+    for sc, chord_c, chord_r in ((scenes.cornell_box(512, 512), (278, 274, 280), 500.0),
+                                 (scenes.sponza_class(256, 144, target_tris=60_000), (16.0, 5.0, 8.0), 30.0)):
+        o = kkoracle.Oracle(sc)
+        with _ctx(gpu, sc, projection_test=True) as ctx:
+            cam, sec = _secondary_rays(o, sc, 300_000, seed=7)
+            chords = helpers.chord_rays(300_000, chord_c, chord_r, seed=4)
+            for rays in (cam, sec, chords):
+                a, b = o.trace(rays), ctx.trace(rays)
+                same = a["prim"] == b["prim"]
+                n_bad = int((~same).sum())
+                assert n_bad <= max(1, int(1e-5 * len(rays))), "%d of %d rays differ" % (n_bad, len(rays))
+                assert helpers.classify_mismatches(sc, rays, a, b) == 0
+                for f in ("t", "u", "v"):
+                    assert np.array_equal(a[f][same].view(np.uint32), b[f][same].view(np.uint32)), f
+                sa, sb = o.trace(rays, any_hit=True), ctx.trace(rays, any_hit=True)
+                occ = ((sa["prim"] != MISS) != (sb["prim"] != MISS)).sum()
+                assert occ <= max(1, int(1e-5 * len(rays))), occ
+            # the integrator on top of it: same image as the oracle with the same sample stream
+            film, _ = ctx.render(4, 1, 1)
+            ref, _ = o.render(4, 1, 1)
+            assert helpers.rel_mse(helpers.develop(film), helpers.develop(ref)) < 1e-4
+
+
 def test_trace_edge_cases(gpu):
     """empty ray set, empty interval, axis-aligned directions, rays through shared edges and vertices (watertight:
     no ray may slip between two triangles of a closed grid), degenerate triangles in the scene."""
