@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override the workload's spp (then the line is not the headline config)")
     ap.add_argument("--scale", type=float, default=1.0, help="resolution scale (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--leaf-test", default="watertight", choices=["watertight", "projection"],
+                    help="projection = KKD_FLAG_PROJECTION_TEST (the reference's TriAccel arithmetic, bit-identical hit ids)")
     ap.add_argument("--batch", type=int, default=0, help="camera samples in flight per batch (0 = library default)")
     args = ap.parse_args()
 
@@ -89,7 +91,8 @@ def main():
         spp = args.spp
     n_b = n_l = 1
     t0 = time.perf_counter()
-    ctx = kkdirect.Context(device=local_rank, seed=1, max_samples_in_flight=args.batch).upload(scene)
+    proj = args.leaf_test == "projection"
+    ctx = kkdirect.Context(device=local_rank, seed=1, max_samples_in_flight=args.batch, projection_test=proj).upload(scene)
     upload_s = time.perf_counter() - t0
     W, H = ctx.width, ctx.height
     film = torch.zeros(H * W * 5, dtype=torch.float32, device="cuda")
@@ -132,7 +135,7 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel: HIP-event stage times of the timed steps (recorded by the library on
         # the stream its kernels run on) against algorithmic bytes from a counting pass of the same traversal ----
-        cctx = kkdirect.Context(device=local_rank, seed=1, count_traversal=True).upload(scene)
+        cctx = kkdirect.Context(device=local_rank, seed=1, count_traversal=True, projection_test=proj).upload(scene)
         _, cst = cctx.render(min(spp, 8), n_b, n_l, tile_index=kw["tile_index"], tile_count=kw["tile_count"])
         cctx.close()
         per_ray = [(cst.class_nodes[k] / max(1, cst.class_rays[k]), cst.class_tris[k] / max(1, cst.class_rays[k])) for k in range(3)]
@@ -169,7 +172,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "mrays_per_s": round(rays / elapsed / 1e6, 3),
             "config": {"workload": label, "spp_total": kw["spp"] if args.split == "tile" else spp * world, "bsdfSamples": n_b, "lightSamples": n_l,
-                       "split": args.split, "triangles": int(scene._nt), "scene_upload_s": round(upload_s, 2)},
+                       "split": args.split, "leaf_test": args.leaf_test, "triangles": int(scene._nt), "scene_upload_s": round(upload_s, 2)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
     ctx.close()
