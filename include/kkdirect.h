@@ -280,6 +280,36 @@ int kkd_probe_rough_transmittance(int distribution, float alpha, float eta, floa
  * ReconstructionFilter::configure (src/libcore/rfilter.cpp:37-55) for the filters of src/rfilters/. */
 int kkd_probe_rfilter(int rfilter_type, float radius, const float *param2, float *values32, float *scale_factor, int *border);
 
+/* ---- film develop and output: the step right after the path ---- */
+
+/* Bitmap::EPixelFormat values the develop step can produce (SPECTRUM_SAMPLES = 3: spectrum = linear RGB) */
+#define KKD_PIXEL_LUMINANCE       0   /* 1 channel  */
+#define KKD_PIXEL_LUMINANCE_ALPHA 1   /* 2 channels */
+#define KKD_PIXEL_RGB             2   /* 3 channels */
+#define KKD_PIXEL_RGBA            3   /* 4 channels */
+#define KKD_PIXEL_XYZ             4   /* 3 channels */
+#define KKD_PIXEL_XYZA            5   /* 4 channels */
+
+/* HDRFilm::develop / MFilm::develop (src/films/hdrfilm.cpp:481-497, src/films/mfilm.cpp:264-265): Bitmap::convert of
+ * the ESpectrumAlphaWeight film {R*w,G*w,B*w,alpha*w,w} to pixel_format, float32, gamma 1, i.e. the
+ * ESpectrumAlphaWeight source branch of FormatConverterImpl::convert (src/libcore/fmtconv.cpp:955-1034):
+ * invWeight = w != 0 ? 1/w : 0, colour and alpha times invWeight, luminance / XYZ by the Rec. 709 weights of
+ * src/libcore/spectrum.cpp:229-234.  dev_film: width*height*5 floats, dev_out: width*height*channels floats, both in
+ * device memory.  The Mitsuba banner (hdrfilm.cpp:493-504) is not drawn. */
+int kkd_develop_device(kkd_ctx *ctx, const void *dev_film, uint32_t width, uint32_t height, int32_t pixel_format, void *dev_out);
+
+/* Same conversion (src/libcore/fmtconv.cpp:955-1034) with film and result in host memory. */
+int kkd_develop(kkd_ctx *ctx, const float *film, uint32_t width, uint32_t height, int32_t pixel_format, float *out);
+
+/* Bitmap::writePFM (src/libcore/bitmap.cpp:3804-3843): "PF" (RGB / RGBA, alpha stripped) or "Pf" (luminance) header,
+ * size, "-1" for little endian, then the scanlines bottom-up as float32.  Host only, no context needed. */
+int kkd_write_pfm(const char *path, const float *pixels, uint32_t width, uint32_t height, int32_t pixel_format);
+
+/* MFilm::develop with fileFormat = numpy (src/films/mfilm.cpp:336-352): a version-1.0 .npy file holding a C-ordered
+ * little-endian float32 array of shape (height, width, channels), or (height, width) when channels == 1, as
+ * cnpy::npy_save writes it.  Host only, no context needed. */
+int kkd_write_npy(const char *path, const float *pixels, uint32_t width, uint32_t height, uint32_t channels);
+
 /* Asynchronous, thread-safe: replaces SamplingIntegrator::cancel (src/librender/integrator.cpp:90-93). */
 void kkd_request_cancel(kkd_ctx *ctx);
 

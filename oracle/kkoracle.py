@@ -209,3 +209,44 @@ def rfilter_table(ftype, radius, param=(0.5, 0.0)):
     p = np.asarray(param, np.float32); v = np.zeros(32, np.float32); s = np.zeros(1, np.float32); b = C.c_int()
     lib().ora_rfilter_table(ftype, radius, _fp(p), _fp(v), _fp(s), C.byref(b))
     return v, float(s[0]), b.value
+
+
+# ---- film develop and output (the step right after the path; ORACLE = test infrastructure only) -----------------
+def develop_film(film, pixel_format="rgb"):
+    """Bitmap::convert(ESpectrumAlphaWeight -> pixel_format, float32, gamma 1) as HDRFilm::develop / MFilm::develop use it
+    (reference src/films/hdrfilm.cpp:481-497, src/films/mfilm.cpp:264-265; conversion src/libcore/fmtconv.cpp:955-1034;
+    Rec. 709 weights src/libcore/spectrum.cpp:229-234).  film: H x W x 5 float32 {R*w, G*w, B*w, alpha*w, w}.
+    Every operation is a separate float32 numpy operation (no fusion), in the reference's order."""
+    f = np.float32
+    film = np.asarray(film, f)
+    r, g, b, a, w = (film[..., k] for k in range(5))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = np.where(w != 0, f(1.0) / w, w).astype(f)
+    fmt = pixel_format.lower()
+    if fmt in ("luminance", "luminancealpha"):
+        lum = ((r * f(0.212671) + g * f(0.715160)) + b * f(0.072169)) * inv
+        ch = [lum] + ([a * inv] if fmt == "luminancealpha" else [])
+    elif fmt in ("rgb", "rgba"):
+        ch = [r * inv, g * inv, b * inv] + ([a * inv] if fmt == "rgba" else [])
+    elif fmt in ("xyz", "xyza"):
+        x, y, z = r * inv, g * inv, b * inv
+        ch = [(x * f(0.412453) + y * f(0.357580)) + z * f(0.180423),
+              (x * f(0.212671) + y * f(0.715160)) + z * f(0.072169),
+              (x * f(0.019334) + y * f(0.119193)) + z * f(0.950227)] + ([a * inv] if fmt == "xyza" else [])
+    else:
+        raise ValueError(pixel_format)
+    return np.stack(ch, -1).astype(f)
+
+
+def pfm_bytes(pixels):
+    """Bitmap::writePFM (reference src/libcore/bitmap.cpp:3804-3843): header 'PF'|'Pf', 'W H', '-1' (little endian), then the
+    scanlines bottom-up; an alpha channel is stripped.  pixels: H x W x {1,3,4} float32."""
+    px = np.asarray(pixels, np.float32)
+    if px.ndim == 2:
+        px = px[..., None]
+    h, w, c = px.shape
+    if c not in (1, 3, 4):
+        raise ValueError("writePFM(): pixel format must be ERGB, ERGBA, ELuminance")
+    head = ("P%s\n%d %d\n-1\n" % ("f" if c == 1 else "F", w, h)).encode()
+    body = px[::-1, :, :3] if c == 4 else px[::-1]
+    return head + np.ascontiguousarray(body).astype("<f4").tobytes()

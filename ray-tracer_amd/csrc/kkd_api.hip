@@ -188,6 +188,46 @@ int kkd_accel_info(kkd_ctx *ctx, uint32_t *node_bytes, uint32_t *tri_bytes, uint
     return KKD_OK;
 }
 
+static int developChannels(int fmt) {
+    switch (fmt) {
+        case KKD_PIXEL_LUMINANCE: return 1;
+        case KKD_PIXEL_LUMINANCE_ALPHA: return 2;
+        case KKD_PIXEL_RGB: case KKD_PIXEL_XYZ: return 3;
+        case KKD_PIXEL_RGBA: case KKD_PIXEL_XYZA: return 4;
+        default: return 0;
+    }
+}
+
+int kkd_develop_device(kkd_ctx *ctx, const void *dev_film, uint32_t width, uint32_t height, int32_t pixel_format, void *dev_out) {
+    if (!ctx) return KKD_ERR_INVALID;
+    if (!developChannels(pixel_format)) return fail(ctx, KKD_ERR_INVALID, "kkd_develop: unknown pixel format");
+    if ((!dev_film || !dev_out) && (uint64_t)width * height != 0) return fail(ctx, KKD_ERR_INVALID, "kkd_develop: null buffer");
+    KKD_HIP(ctx, hipSetDevice(ctx->device));
+    launchDevelop(ctx->stream, (const float *)dev_film, (uint64_t)width * height, pixel_format, (float *)dev_out);
+    KKD_HIP(ctx, hipGetLastError());
+    KKD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KKD_OK;
+}
+
+int kkd_develop(kkd_ctx *ctx, const float *film, uint32_t width, uint32_t height, int32_t pixel_format, float *out) {
+    if (!ctx) return KKD_ERR_INVALID;
+    const int ch = developChannels(pixel_format);
+    if (!ch) return fail(ctx, KKD_ERR_INVALID, "kkd_develop: unknown pixel format");
+    const uint64_t n = (uint64_t)width * height;
+    if (n == 0) return KKD_OK;
+    if (!film || !out) return fail(ctx, KKD_ERR_INVALID, "kkd_develop: null buffer");
+    KKD_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = ctx->film.ensure(n * 5 * sizeof(float));
+    if (e == hipSuccess) e = ctx->apiHits.ensure(n * ch * sizeof(float));
+    if (e != hipSuccess) { ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e); return e == hipErrorOutOfMemory ? KKD_ERR_NOMEM : KKD_ERR_DEVICE; }
+    KKD_HIP(ctx, hipMemcpyAsync(ctx->film.p, film, n * 5 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    launchDevelop(ctx->stream, (const float *)ctx->film.p, n, pixel_format, (float *)ctx->apiHits.p);
+    KKD_HIP(ctx, hipGetLastError());
+    KKD_HIP(ctx, hipMemcpyAsync(out, ctx->apiHits.p, n * ch * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    KKD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KKD_OK;
+}
+
 static DeviceCounters sumShards(const std::vector<DeviceCounters> &shards) {
     DeviceCounters c; std::memset(&c, 0, sizeof(c));
     for (const DeviceCounters &s : shards) {

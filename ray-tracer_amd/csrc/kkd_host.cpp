@@ -486,3 +486,59 @@ bool flattenScene(const kkd_scene_desc *sd, HostScene &hs, std::string &err, int
 }
 
 } /* namespace kkd */
+
+/* ---- film output (host only) ------------------------------------------------------------------------------------ */
+#include <cstdio>
+extern "C" {
+
+/* Bitmap::writePFM, src/libcore/bitmap.cpp:3804-3843 */
+int kkd_write_pfm(const char *path, const float *pixels, uint32_t width, uint32_t height, int32_t pixel_format) {
+    if (!path || (!pixels && (uint64_t)width * height != 0)) return KKD_ERR_INVALID;
+    int ch;
+    switch (pixel_format) {
+        case KKD_PIXEL_LUMINANCE: ch = 1; break;
+        case KKD_PIXEL_RGB: ch = 3; break;
+        case KKD_PIXEL_RGBA: ch = 4; break;
+        default: return KKD_ERR_INVALID;   /* "pixel format must be ERGB, ERGBA, ELuminance" */
+    }
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return KKD_ERR_INVALID;
+    const uint16_t one = 1; const bool little = *reinterpret_cast<const uint8_t *>(&one) == 1;
+    std::fprintf(f, "P%c\n%u %u\n%s\n", ch == 1 ? 'f' : 'F', width, height, little ? "-1" : "1");
+    bool ok = true;
+    const size_t scan = (size_t)width * ch;
+    std::vector<float> tmp(ch == 4 ? (size_t)width * 3 : 0);
+    for (uint32_t y = 0; y < height && ok; ++y) {
+        const float *src = pixels + scan * (height - 1 - y);
+        if (ch != 4) ok = std::fwrite(src, sizeof(float), scan, f) == scan;
+        else {      /* the alpha channel is stripped while saving */
+            for (uint32_t x = 0; x < width; ++x) { tmp[3 * x] = src[4 * x]; tmp[3 * x + 1] = src[4 * x + 1]; tmp[3 * x + 2] = src[4 * x + 2]; }
+            ok = std::fwrite(tmp.data(), sizeof(float), tmp.size(), f) == tmp.size();
+        }
+    }
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? KKD_OK : KKD_ERR_INVALID;
+}
+
+/* MFilm::develop, numpy branch (src/films/mfilm.cpp:336-352): cnpy::npy_save of a float array, shape (H, W[, C]) */
+int kkd_write_npy(const char *path, const float *pixels, uint32_t width, uint32_t height, uint32_t channels) {
+    if (!path || channels == 0 || (!pixels && (uint64_t)width * height != 0)) return KKD_ERR_INVALID;
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return KKD_ERR_INVALID;
+    char dict[160];
+    if (channels == 1) std::snprintf(dict, sizeof(dict), "{'descr': '<f4', 'fortran_order': False, 'shape': (%u, %u), }", height, width);
+    else std::snprintf(dict, sizeof(dict), "{'descr': '<f4', 'fortran_order': False, 'shape': (%u, %u, %u), }", height, width, channels);
+    std::string hdr(dict);
+    /* magic (6) + version (2) + header length (2) + dict, padded with spaces to a multiple of 16, ending in a newline */
+    while ((10 + hdr.size() + 1) % 16 != 0) hdr.push_back(' ');
+    hdr.push_back('\n');
+    const unsigned char magic[8] = { 0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0 };
+    const unsigned char len[2] = { (unsigned char)(hdr.size() & 0xff), (unsigned char)(hdr.size() >> 8) };
+    bool ok = std::fwrite(magic, 1, 8, f) == 8 && std::fwrite(len, 1, 2, f) == 2 && std::fwrite(hdr.data(), 1, hdr.size(), f) == hdr.size();
+    const size_t n = (size_t)width * height * channels;
+    ok = ok && std::fwrite(pixels, sizeof(float), n, f) == n;
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? KKD_OK : KKD_ERR_INVALID;
+}
+
+} /* extern "C" */

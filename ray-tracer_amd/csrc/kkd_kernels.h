@@ -43,6 +43,7 @@ void launchPrimary(hipStream_t st, bool count, const DScene &sc, const BatchPara
 /* rayClass: which DeviceCounters slot the launch accounts to */
 void launchTrace(hipStream_t st, const DScene &sc, const DRay *rays, uint64_t n, bool anyHit, bool count, int outMode, void *out, DeviceCounters *ctr, int rayClass);
 void launchShade(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb);
+void launchDevelop(hipStream_t st, const float *film, uint64_t nPixels, int pixelFormat, float *out);
 void launchResolve(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb, float *film, DeviceCounters *ctr);
 
 } /* namespace kkd */

@@ -369,6 +369,33 @@ __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveB
     if (ctr) countRays(s.active, &counterShard(ctr)->samples);
 }
 
+/* ---- film develop: Bitmap::convert(ESpectrumAlphaWeight -> fmt), src/libcore/fmtconv.cpp:955-1034 ----------------
+ * One pixel per lane: 20 bytes in, 4-16 bytes out, HBM streaming.  Operation order of the reference, unfused. */
+template <int FMT>
+__global__ void __launch_bounds__(256) kDevelop(const float *__restrict__ film, uint64_t n, float *__restrict__ out) {
+#pragma clang fp contract(off)
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *p = film + i * 5;
+    const float r = p[0], g = p[1], b = p[2], a = p[3], w = p[4];
+    const float inv = (w != 0.f) ? 1.0f / w : w;
+    constexpr int C = (FMT == KKD_PIXEL_LUMINANCE) ? 1 : (FMT == KKD_PIXEL_LUMINANCE_ALPHA) ? 2 : (FMT == KKD_PIXEL_RGB || FMT == KKD_PIXEL_XYZ) ? 3 : 4;
+    float *o = out + i * C;
+    if (FMT == KKD_PIXEL_LUMINANCE || FMT == KKD_PIXEL_LUMINANCE_ALPHA) {
+        o[0] = (r * 0.212671f + g * 0.715160f + b * 0.072169f) * inv;      /* spec.getLuminance() * invWeight */
+        if (FMT == KKD_PIXEL_LUMINANCE_ALPHA) o[1] = a * inv;
+    } else if (FMT == KKD_PIXEL_RGB || FMT == KKD_PIXEL_RGBA) {
+        o[0] = r * inv; o[1] = g * inv; o[2] = b * inv;                     /* Spectrum(spec * invWeight).toLinearRGB */
+        if (FMT == KKD_PIXEL_RGBA) o[3] = a * inv;
+    } else {
+        const float x = r * inv, y = g * inv, z = b * inv;                  /* Spectrum(spec * invWeight * 1).toXYZ, spectrum.cpp:229-234 */
+        o[0] = x * 0.412453f + y * 0.357580f + z * 0.180423f;
+        o[1] = x * 0.212671f + y * 0.715160f + z * 0.072169f;
+        o[2] = x * 0.019334f + y * 0.119193f + z * 0.950227f;
+        if (FMT == KKD_PIXEL_XYZA) o[3] = a * inv;
+    }
+}
+
 /* ---- host launchers ---------------------------------------------------------------------------------- */
 static inline uint32_t blocksFor(uint64_t n, uint32_t block) { return (uint32_t)((n + block - 1) / block); }
 
@@ -402,6 +429,19 @@ void launchTrace(hipStream_t st, const DScene &sc, const DRay *rays, uint64_t n,
 
 void launchShade(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb) {
     hipLaunchKernelGGL(kShade, dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, wb);
+}
+
+void launchDevelop(hipStream_t st, const float *film, uint64_t n, int fmt, float *out) {
+    if (n == 0) return;
+    const dim3 grid(blocksFor(n, 256)), block(256);
+    switch (fmt) {
+        case KKD_PIXEL_LUMINANCE: hipLaunchKernelGGL(kDevelop<KKD_PIXEL_LUMINANCE>, grid, block, 0, st, film, n, out); break;
+        case KKD_PIXEL_LUMINANCE_ALPHA: hipLaunchKernelGGL(kDevelop<KKD_PIXEL_LUMINANCE_ALPHA>, grid, block, 0, st, film, n, out); break;
+        case KKD_PIXEL_RGB: hipLaunchKernelGGL(kDevelop<KKD_PIXEL_RGB>, grid, block, 0, st, film, n, out); break;
+        case KKD_PIXEL_RGBA: hipLaunchKernelGGL(kDevelop<KKD_PIXEL_RGBA>, grid, block, 0, st, film, n, out); break;
+        case KKD_PIXEL_XYZ: hipLaunchKernelGGL(kDevelop<KKD_PIXEL_XYZ>, grid, block, 0, st, film, n, out); break;
+        default: hipLaunchKernelGGL(kDevelop<KKD_PIXEL_XYZA>, grid, block, 0, st, film, n, out); break;
+    }
 }
 
 void launchResolve(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb, float *film, DeviceCounters *ctr) {

@@ -127,14 +127,53 @@ class Context:
         self._check(self.lib.kkd_trace_device(self.h, C.c_void_p(dev_rays), n, int(any_hit), C.c_void_p(dev_out), C.byref(st)))
         return st
 
+    def develop(self, film, pixel_format="rgb"):
+        """HDRFilm::develop / MFilm::develop on the GPU: film H x W x 5 -> H x W x channels float32 (kkd_develop)."""
+        fmt = abi.PIXEL_FORMATS[pixel_format.lower()] if isinstance(pixel_format, str) else int(pixel_format)
+        film = np.ascontiguousarray(film, np.float32)
+        h, w = film.shape[0], film.shape[1]
+        out = np.zeros((h, w, abi.PIXEL_CHANNELS.get(fmt, 4)), np.float32)   # an unknown format is the library's to reject
+        self._check(self.lib.kkd_develop(self.h, film.ctypes.data_as(abi.pf32), w, h, fmt, out.ctypes.data_as(abi.pf32)))
+        return out
+
+    def develop_device(self, dev_film, width, height, dev_out, pixel_format="rgb"):
+        fmt = abi.PIXEL_FORMATS[pixel_format.lower()] if isinstance(pixel_format, str) else int(pixel_format)
+        self._check(self.lib.kkd_develop_device(self.h, C.c_void_p(dev_film), width, height, fmt, C.c_void_p(dev_out)))
+
     def request_cancel(self):
         self.lib.kkd_request_cancel(self.h)
 
 
 def develop(film):
-    """HDRFilm::develop's normalisation (reference src/films/hdrfilm.cpp:446-450): RGB / weight."""
+    """HDRFilm::develop's normalisation on the host (reference src/libcore/fmtconv.cpp:978-989): RGB * (w != 0 ? 1/w : 0)."""
+    film = np.asarray(film, np.float32)
     w = film[..., 4:5]
-    return np.where(w > 0, film[..., :3] / np.maximum(w, 1e-30), 0.0).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = np.where(w != 0, np.float32(1.0) / w, w).astype(np.float32)
+    return (film[..., :3] * inv).astype(np.float32)
+
+
+def write_pfm(path, pixels, pixel_format=None):
+    """Bitmap::writePFM (reference src/libcore/bitmap.cpp:3804-3843) through kkd_write_pfm; pixels H x W [x C]."""
+    px = np.ascontiguousarray(pixels, np.float32)
+    if px.ndim == 2:
+        px = px[..., None]
+    h, w, c = px.shape
+    fmt = {1: abi.PIXEL_LUMINANCE, 3: abi.PIXEL_RGB, 4: abi.PIXEL_RGBA}.get(c, -1) if pixel_format is None else abi.PIXEL_FORMATS[pixel_format.lower()]
+    rc = load_library().kkd_write_pfm(os.fsencode(path), px.ctypes.data_as(abi.pf32), w, h, fmt)
+    if rc != 0:
+        raise KKDError(rc, "kkd_write_pfm(%s) failed" % path)
+
+
+def write_npy(path, pixels):
+    """MFilm's numpy output (reference src/films/mfilm.cpp:336-352) through kkd_write_npy; pixels H x W [x C]."""
+    px = np.ascontiguousarray(pixels, np.float32)
+    if px.ndim == 2:
+        px = px[..., None]
+    h, w, c = px.shape
+    rc = load_library().kkd_write_npy(os.fsencode(path), px.ctypes.data_as(abi.pf32), w, h, c)
+    if rc != 0:
+        raise KKDError(rc, "kkd_write_npy(%s) failed" % path)
 
 
 class DirectIntegrator:

@@ -16,6 +16,10 @@ RFILTER_GAUSSIAN, RFILTER_BOX, RFILTER_TENT, RFILTER_MITCHELL, RFILTER_CATMULLRO
 SHAPE_HAS_NORMALS, SHAPE_HAS_TEXCOORDS = 1, 2
 FLAG_COUNT_TRAVERSAL = 1
 FLAG_PROJECTION_TEST = 2
+PIXEL_LUMINANCE, PIXEL_LUMINANCE_ALPHA, PIXEL_RGB, PIXEL_RGBA, PIXEL_XYZ, PIXEL_XYZA = range(6)
+PIXEL_CHANNELS = {PIXEL_LUMINANCE: 1, PIXEL_LUMINANCE_ALPHA: 2, PIXEL_RGB: 3, PIXEL_RGBA: 4, PIXEL_XYZ: 3, PIXEL_XYZA: 4}
+PIXEL_FORMATS = {"luminance": PIXEL_LUMINANCE, "luminancealpha": PIXEL_LUMINANCE_ALPHA, "rgb": PIXEL_RGB, "rgba": PIXEL_RGBA,
+                 "xyz": PIXEL_XYZ, "xyza": PIXEL_XYZA}
 RAYS_PRIMARY, RAYS_BSDF, RAYS_SHADOW = 0, 1, 2
 STAGE_NAMES = ("primary", "shade", "bsdf", "shadow", "resolve")
 
@@ -95,6 +99,10 @@ ENTRY_POINTS = {
     "kkd_accel_info": (C.c_int, [C.c_void_p, pu32, pu32, C.POINTER(u64), C.POINTER(u64)]),
     "kkd_probe_rough_transmittance": (C.c_int, [C.c_int, C.c_float, C.c_float, pf32, pf32]),
     "kkd_probe_rfilter": (C.c_int, [C.c_int, C.c_float, pf32, pf32, pf32, C.POINTER(C.c_int)]),
+    "kkd_develop_device": (C.c_int, [C.c_void_p, C.c_void_p, u32, u32, i32, C.c_void_p]),
+    "kkd_develop": (C.c_int, [C.c_void_p, pf32, u32, u32, i32, pf32]),
+    "kkd_write_pfm": (C.c_int, [C.c_char_p, pf32, u32, u32, i32]),
+    "kkd_write_npy": (C.c_int, [C.c_char_p, pf32, u32, u32, u32]),
     "kkd_request_cancel": (None, [C.c_void_p]),
     "kkd_last_error": (C.c_char_p, [C.c_void_p]),
     "kkd_destroy": (None, [C.c_void_p]),

@@ -1,0 +1,90 @@
+"""Film develop and output (the step right after the path).
+CPU tests: the host-only writers against the oracle's byte-level restatement of Bitmap::writePFM and against numpy's own
+.npy reader.  GPU tests: kkd_develop / kkd_develop_device bit-exact against the oracle's restatement of
+Bitmap::convert(ESpectrumAlphaWeight -> fmt)."""
+import numpy as np
+import pytest
+import kkoracle
+import kkdirect
+from kkdirect import abi, scenes
+
+FORMATS = ["luminance", "luminanceAlpha", "rgb", "rgba", "xyz", "xyza"]
+
+
+def _film(h, w, seed):
+    rng = np.random.RandomState(seed)
+    wgt = rng.rand(h, w, 1).astype(np.float32) * 40
+    wgt[rng.rand(h, w) < 0.1] = 0.0                       # pixels no sample touched: invWeight = 0
+    rgb = (rng.rand(h, w, 3).astype(np.float32) ** 4) * 1e3
+    alpha = rng.rand(h, w, 1).astype(np.float32)
+    film = np.concatenate([rgb * wgt, alpha * wgt, wgt], -1).astype(np.float32)
+    film[0, 0] = [1, 2, 3, 1, 0]                           # colour without weight stays colour * 0
+    return film
+
+
+@pytest.mark.parametrize("shape", [(7, 5, 3), (4, 9, 1), (3, 3, 4), (1, 1, 3)])
+def test_write_pfm_bytes(tmp_path, shape):
+    img = np.random.RandomState(1).randn(*shape).astype(np.float32)
+    path = tmp_path / "out.pfm"
+    kkdirect.write_pfm(str(path), img)
+    assert path.read_bytes() == kkoracle.pfm_bytes(img)
+
+
+def test_write_pfm_rejects_other_formats(tmp_path):
+    with pytest.raises(kkdirect.KKDError):
+        kkdirect.write_pfm(str(tmp_path / "x.pfm"), np.zeros((2, 2, 2), np.float32))          # luminanceAlpha: not a PFM format
+    with pytest.raises(kkdirect.KKDError):
+        kkdirect.write_pfm(str(tmp_path / "nodir" / "x.pfm"), np.zeros((2, 2, 3), np.float32))
+
+
+@pytest.mark.parametrize("shape", [(6, 4, 3), (5, 8, 1), (2, 3, 4), (300, 200, 2)])
+def test_write_npy_roundtrip(tmp_path, shape):
+    img = np.random.RandomState(2).randn(*shape).astype(np.float32)
+    path = tmp_path / "out.npy"
+    kkdirect.write_npy(str(path), img)
+    back = np.load(str(path), allow_pickle=False)
+    assert back.dtype == np.float32 and not np.isfortran(back)
+    assert back.shape == (shape[:2] if shape[2] == 1 else shape)                              # mfilm.cpp:343-344: N = 2 for one channel
+    assert np.array_equal(back.reshape(shape), img)
+    raw = path.read_bytes()
+    assert raw[:8] == b"\x93NUMPY\x01\x00" and (10 + int.from_bytes(raw[8:10], "little")) % 16 == 0
+
+
+def test_oracle_develop_known_answers():
+    film = np.array([[[2, 4, 6, 1, 2], [1, 1, 1, 1, 0], [0.5, 0.25, 0.125, 0.5, 0.5]]], np.float32)
+    rgba = kkoracle.develop_film(film, "rgba")
+    assert np.array_equal(rgba, np.array([[[1, 2, 3, 0.5], [0, 0, 0, 0], [1, 0.5, 0.25, 1]]], np.float32))
+    lum = kkoracle.develop_film(film, "luminance")
+    np.testing.assert_allclose(lum[0, :, 0], [0.212671 + 2 * 0.715160 + 3 * 0.072169, 0, 0.212671 + 0.5 * 0.715160 + 0.25 * 0.072169], rtol=1e-6)
+    xyz = kkoracle.develop_film(film, "xyz")
+    assert np.array_equal(xyz[..., 1], lum[..., 0]) or np.allclose(xyz[..., 1], lum[..., 0], rtol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_develop_bit_exact(gpu, fmt):
+    film = _film(97, 131, seed=3)
+    with gpu.Context(device=0) as ctx:
+        out = ctx.develop(film, fmt)
+    ref = kkoracle.develop_film(film, fmt)
+    assert out.shape == ref.shape
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_develop_device_on_rendered_film(gpu, tmp_path):
+    import torch
+    sc = scenes.cornell_box(64, 64)
+    with gpu.Context(device=0).upload(sc) as ctx:
+        film = torch.zeros(64 * 64 * 5, dtype=torch.float32, device="cuda")
+        ctx.render_device(film.data_ptr(), spp=16)
+        rgb = torch.zeros(64 * 64 * 3, dtype=torch.float32, device="cuda")
+        ctx.develop_device(film.data_ptr(), 64, 64, rgb.data_ptr(), "rgb")
+        host = film.cpu().numpy().reshape(64, 64, 5)
+        out = rgb.cpu().numpy().reshape(64, 64, 3)
+        assert np.array_equal(out.view(np.uint32), kkoracle.develop_film(host, "rgb").view(np.uint32))
+        assert np.array_equal(out, kkdirect.develop(host))                                    # the Python mirror agrees
+        with pytest.raises(kkdirect.KKDError):
+            ctx.develop(host, 17)
+    kkdirect.write_pfm(str(tmp_path / "cbox.pfm"), out)
+    assert (tmp_path / "cbox.pfm").read_bytes() == kkoracle.pfm_bytes(out)
