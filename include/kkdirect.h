@@ -310,6 +310,48 @@ int kkd_write_pfm(const char *path, const float *pixels, uint32_t width, uint32_
  * cnpy::npy_save writes it.  Host only, no context needed. */
 int kkd_write_npy(const char *path, const float *pixels, uint32_t width, uint32_t height, uint32_t channels);
 
+/* ---- on-disk mesh formats: the step right before the path ---- */
+
+#define KKD_MESH_FACE_NORMALS 1u   /* TriMesh::m_faceNormals: shade with face normals (EFaceNormals, src/librender/trimesh.cpp:93) */
+
+/* One triangle mesh as TriMesh holds it (src/librender/trimesh.cpp:39-54); the arrays are malloc'ed by the loader
+ * and released by kkd_mesh_free.  They are laid out as kkd_scene_desc wants them. */
+typedef struct kkd_mesh {
+    uint64_t  n_verts, n_tris;
+    float    *positions;      /* n_verts * 3                                     */
+    float    *normals;        /* n_verts * 3 or NULL                             */
+    float    *texcoords;      /* n_verts * 2 or NULL                             */
+    float    *colors;         /* n_verts * 3 or NULL (vertex colours, linear RGB) */
+    uint32_t *indices;        /* n_tris * 3                                      */
+    uint32_t  flags;          /* KKD_MESH_*                                      */
+    uint32_t  reserved;
+    float     aabb_min[3], aabb_max[3];
+    char      name[256];
+} kkd_mesh;
+
+/* Number of meshes in a .serialized file: TriMesh::readOffsetDictionary (src/librender/trimesh.cpp:296-337); a file
+ * without a valid dictionary holds one mesh (src/shapes/serialized.cpp:232-236). */
+int kkd_mesh_count_serialized(const char *path, uint32_t *count);
+
+/* The serialized plugin: TriMesh::loadCompressed (src/librender/trimesh.cpp:174-249; versions 3 and 4, single or
+ * double precision, zlib stream) for sub-mesh shape_index, then the toWorld handling of SerializedMesh
+ * (src/shapes/serialized.cpp:183-201: points, normalised normals, winding flipped when det < 0).  to_world: 16 floats
+ * row-major or NULL.  Errors: kkd_last_error(NULL). */
+int kkd_mesh_load_serialized(const char *path, int32_t shape_index, const float *to_world, kkd_mesh *out);
+
+/* The .serialized writer, TriMesh::serialize(Stream*) (src/librender/trimesh.cpp:1060-1108), version 4, single
+ * precision, followed by the offset dictionary that readOffsetDictionary (trimesh.cpp:296-337) reads back. */
+int kkd_mesh_save_serialized(const char *path, const kkd_mesh *meshes, uint32_t n_meshes);
+
+/* The ply plugin, PLYLoader (src/shapes/ply.cpp:96-330, property mapping :326-470): ascii and both binary formats;
+ * float32 x/y/z, nx/ny/nz, u|texture_u|s, v|texture_v|t, [diffuse_]red/green/blue as float32 or uint8 (sRGB -> linear
+ * when srgb != 0); faces "vertex_indices" | "vertex_index" with a uint8 / uint32 count and int32 / uint32 indices,
+ * triangles and quads (a quad becomes (0,1,2) + (3,0,2)); properties of other types are skipped as libply does. */
+int kkd_mesh_load_ply(const char *path, const float *to_world, int32_t srgb, kkd_mesh *out);
+
+/* Releases the arrays of a loaded mesh (the reference frees them in TriMesh::~TriMesh, src/librender/trimesh.cpp:339-352). */
+void kkd_mesh_free(kkd_mesh *mesh);
+
 /* Asynchronous, thread-safe: replaces SamplingIntegrator::cancel (src/librender/integrator.cpp:90-93). */
 void kkd_request_cancel(kkd_ctx *ctx);
 

@@ -250,3 +250,195 @@ def pfm_bytes(pixels):
     head = ("P%s\n%d %d\n-1\n" % ("f" if c == 1 else "F", w, h)).encode()
     body = px[::-1, :, :3] if c == 4 else px[::-1]
     return head + np.ascontiguousarray(body).astype("<f4").tobytes()
+
+
+# ---- on-disk mesh formats (the step right before the path; ORACLE = test infrastructure only) ---------------------
+import struct as _struct
+import zlib as _zlib
+
+_SER_HEADER, _SER_V3, _SER_V4 = 0x041C, 3, 4                    # reference src/librender/trimesh.cpp:33-35
+_F_NORMALS, _F_UV, _F_COLORS, _F_FACEN, _F_SINGLE, _F_DOUBLE = 0x1, 0x2, 0x8, 0x10, 0x1000, 0x2000   # trimesh.cpp:88-96
+
+
+def _xform(to_world, pos, nrm, idx=None):
+    """SerializedMesh's toWorld handling (reference src/shapes/serialized.cpp:183-201), float32 like the reference's Float"""
+    if to_world is None or np.array_equal(np.asarray(to_world, np.float32).reshape(4, 4), np.eye(4, dtype=np.float32)):
+        return pos, nrm, idx
+    m = np.asarray(to_world, np.float32).reshape(4, 4)
+    f = np.float32
+    x = ((m[0, 0] * pos[:, 0] + m[0, 1] * pos[:, 1]) + m[0, 2] * pos[:, 2]) + m[0, 3]
+    y = ((m[1, 0] * pos[:, 0] + m[1, 1] * pos[:, 1]) + m[1, 2] * pos[:, 2]) + m[1, 3]
+    z = ((m[2, 0] * pos[:, 0] + m[2, 1] * pos[:, 1]) + m[2, 2] * pos[:, 2]) + m[2, 3]
+    w = ((m[3, 0] * pos[:, 0] + m[3, 1] * pos[:, 1]) + m[3, 2] * pos[:, 2]) + m[3, 3]
+    out = np.stack([x, y, z], 1).astype(f)
+    div = w != f(1)
+    out[div] = (out[div] / w[div, None]).astype(f)
+    if nrm is not None:
+        inv_t = np.linalg.inv(m[:3, :3].astype(np.float64)).T.astype(f)
+        n = (nrm @ inv_t.T).astype(f)
+        ln = np.sqrt((n * n).sum(1, keepdims=True))
+        nrm = np.where(ln > 0, n / np.where(ln > 0, ln, 1), n).astype(f)
+    if idx is not None and np.linalg.det(m[:3, :3].astype(np.float64)) < 0:
+        idx = idx.copy(); idx[:, [0, 1]] = idx[:, [1, 0]]
+    return out, nrm, idx
+
+
+def load_serialized(path, shape_index=0, to_world=None):
+    """TriMesh::loadCompressed + readOffsetDictionary (reference src/librender/trimesh.cpp:174-337) and the serialized plugin's
+    post-processing (src/shapes/serialized.cpp:183-201)."""
+    raw = open(path, "rb").read()
+    fmt, version = _struct.unpack_from("<HH", raw, 0)
+    if fmt != _SER_HEADER or version not in (_SER_V3, _SER_V4):
+        raise ValueError("invalid serialized mesh header")
+    count = _struct.unpack_from("<I", raw, len(raw) - 4)[0]
+    min_size = 4 + count * (2 * 2 + 4 + 1 + 2 * 8 + 3 * 4 + 3 * 4)
+    offset = 0
+    if count > 0 and len(raw) >= min_size:
+        if shape_index >= count:
+            raise ValueError("shape index out of range")
+        if version == _SER_V4:
+            offset = _struct.unpack_from("<Q", raw, len(raw) - 8 * count - 4 + 8 * shape_index)[0]
+        else:
+            offset = _struct.unpack_from("<I", raw, len(raw) - 4 * (count + 1) + 4 * shape_index)[0]
+    elif shape_index != 0:
+        raise ValueError("shape index out of range")
+    fmt, version = _struct.unpack_from("<HH", raw, offset)
+    data = _zlib.decompressobj(15).decompress(raw[offset + 4:])
+    p = 0
+    flags = _struct.unpack_from("<I", data, p)[0]; p += 4
+    name = ""
+    if version == _SER_V4:
+        e = data.index(b"\0", p); name = data[p:e].decode(errors="replace"); p = e + 1
+    nv, nt = _struct.unpack_from("<QQ", data, p); p += 16
+    ft = "<f8" if flags & _F_DOUBLE else "<f4"
+
+    def floats(k):
+        nonlocal p
+        a = np.frombuffer(data, ft, nv * k, p).astype(np.float32).reshape(nv, k); p += nv * k * (8 if flags & _F_DOUBLE else 4)
+        return a
+    pos = floats(3)
+    nrm = floats(3) if flags & _F_NORMALS else None
+    uv = floats(2) if flags & _F_UV else None
+    col = floats(3) if flags & _F_COLORS else None
+    idx = np.frombuffer(data, "<u4", nt * 3, p).reshape(nt, 3).copy()
+    pos, nrm, idx = _xform(to_world, pos, nrm, idx)
+    return {"name": name, "positions": pos, "normals": nrm, "texcoords": uv, "colors": col, "indices": idx, "face_normals": bool(flags & _F_FACEN)}
+
+
+def save_serialized(path, meshes, version=4, double=False, dictionary=True):
+    """TriMesh::serialize(Stream*) (reference src/librender/trimesh.cpp:1060-1108); version 3 = the same stream without the
+    name and with a 32-bit dictionary (what readOffset / loadCompressed accept, trimesh.cpp:190-191, 285-289)."""
+    out = bytearray(); offsets = []
+    ft = "<f8" if double else "<f4"
+    for m in meshes:
+        offsets.append(len(out))
+        out += _struct.pack("<HH", _SER_HEADER, version)
+        flags = _F_DOUBLE if double else _F_SINGLE
+        flags |= (_F_NORMALS if m.get("normals") is not None else 0) | (_F_UV if m.get("texcoords") is not None else 0)
+        flags |= (_F_COLORS if m.get("colors") is not None else 0) | (_F_FACEN if m.get("face_normals") else 0)
+        body = _struct.pack("<I", flags)
+        if version == _SER_V4:
+            body += m.get("name", "").encode() + b"\0"
+        body += _struct.pack("<QQ", len(m["positions"]), len(m["indices"]))
+        for key in ("positions", "normals", "texcoords", "colors"):
+            if m.get(key) is not None:
+                body += np.ascontiguousarray(m[key]).astype(ft).tobytes()
+        body += np.ascontiguousarray(m["indices"]).astype("<u4").tobytes()
+        out += _zlib.compress(body)
+    if dictionary:
+        for o in offsets:
+            out += _struct.pack("<Q" if version == _SER_V4 else "<I", o)
+        out += _struct.pack("<I", len(meshes))
+    open(path, "wb").write(bytes(out))
+
+
+_PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2", "uint16": "u2",
+              "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4", "double": "f8", "float64": "f8"}
+
+
+def load_ply(path, to_world=None, srgb=True):
+    """PLYLoader (reference src/shapes/ply.cpp:96-330, 326-470), value by value (slow; small test files only)."""
+    raw = open(path, "rb").read()
+    head_end = raw.index(b"end_header") + len(b"end_header")
+    head_end = raw.index(b"\n", head_end) + 1
+    lines = [l.strip() for l in raw[:head_end].decode("ascii", "replace").splitlines()]
+    assert lines[0] == "ply"
+    mode = None; elems = []
+    for l in lines[1:]:
+        t = l.split()
+        if not t:
+            continue
+        if t[0] == "format":
+            mode = t[1]
+        elif t[0] == "element":
+            elems.append([t[1], int(t[2]), []])
+        elif t[0] == "property":
+            elems[-1][2].append(("list", _PLY_TYPES[t[2]], _PLY_TYPES[t[3]], t[4]) if t[1] == "list" else ("scalar", _PLY_TYPES[t[1]], None, t[2]))
+    body = raw[head_end:]
+    if mode == "ascii":
+        toks = body.split(); ti = 0
+
+        def rd(tp):
+            nonlocal ti
+            v = toks[ti]; ti += 1
+            return float(v) if tp[0] == "f" else int(v)
+    else:
+        bo = "<" if mode == "binary_little_endian" else ">"; off = 0
+
+        def rd(tp):
+            nonlocal off
+            v = np.frombuffer(body, bo + tp, 1, off)[0]; off += int(tp[1])
+            return v
+    slots = {"x": 0, "y": 1, "z": 2, "nx": 3, "ny": 4, "nz": 5, "u": 6, "texture_u": 6, "s": 6, "v": 7, "texture_v": 7, "t": 7,
+             "red": 8, "diffuse_red": 8, "green": 9, "diffuse_green": 9, "blue": 10, "diffuse_blue": 10}
+    pos = nrm = uv = col = None; tris = []
+    for name, count, props in elems:
+        if name == "vertex":
+            used = [slots.get(pn, -1) if (tp == "f4" or (tp == "u1" and slots.get(pn, -1) >= 8)) and kind == "scalar" else -1 for kind, tp, _, pn in props]
+            cur = np.zeros(11, np.float32); rows = np.zeros((count, 11), np.float32)
+            for v in range(count):
+                for (kind, tp, it, pn), s in zip(props, used):
+                    if kind == "list":
+                        for _ in range(int(rd(tp))):
+                            rd(it)
+                        continue
+                    val = rd(tp)
+                    if s >= 0:
+                        cur[s] = np.float32(val) / np.float32(255.0) if tp == "u1" else np.float32(val)
+                rows[v] = cur
+            pos = rows[:, 0:3].copy()
+            nrm = rows[:, 3:6].copy() if any(3 <= s <= 5 for s in used) else None
+            uv = rows[:, 6:8].copy() if any(s in (6, 7) for s in used) else None
+            col = rows[:, 8:11].copy() if any(s >= 8 for s in used) else None
+        elif name == "face":
+            for _ in range(count):
+                for kind, tp, it, pn in props:
+                    if kind == "scalar":
+                        rd(tp); continue
+                    n = int(rd(tp)); vals = [int(rd(it)) for _ in range(n)]
+                    if pn in ("vertex_indices", "vertex_index") and tp in ("u1", "u4") and it in ("i4", "u4"):
+                        if n not in (3, 4):
+                            raise ValueError("Only triangle and quad-based PLY meshes are supported")
+                        tris.append(vals[:3])
+                        if n == 4:
+                            tris.append([vals[3], vals[0], vals[2]])
+        else:
+            for _ in range(count):
+                for kind, tp, it, pn in props:
+                    if kind == "scalar":
+                        rd(tp)
+                    else:
+                        for _ in range(int(rd(tp))):
+                            rd(it)
+    if pos is None or not tris:
+        raise ValueError("no triangles or vertices found")
+    if nrm is not None:
+        ident = to_world is None or np.array_equal(np.asarray(to_world, np.float32).reshape(4, 4), np.eye(4, dtype=np.float32))
+        if ident:
+            ln = np.sqrt((nrm * nrm).sum(1, keepdims=True)); nrm = np.where(ln > 0, nrm / np.where(ln > 0, ln, 1), nrm).astype(np.float32)
+    pos, nrm, _ = _xform(to_world, pos, nrm)
+    if col is not None and srgb:
+        c = col
+        col = np.where(c <= np.float32(0.04045), c / np.float32(12.92), ((c + np.float32(0.055)) / np.float32(1.0 + 0.055)) ** np.float32(2.4)).astype(np.float32)
+    return {"name": os.path.splitext(os.path.basename(path))[0], "positions": pos, "normals": nrm, "texcoords": uv, "colors": col,
+            "indices": np.array(tris, np.uint32), "face_normals": False}

@@ -21,7 +21,6 @@ using namespace kkd;
 
 namespace {
 
-std::string g_createError = "";
 
 struct DevBuf {
     void *p = nullptr; size_t bytes = 0;
@@ -76,17 +75,17 @@ int kkd_device_count(void) {
 }
 
 kkd_ctx *kkd_create(const kkd_config *cfg) {
-    if (!cfg) { g_createError = "kkd_create: config is NULL"; return nullptr; }
+    if (!cfg) { g_globalError = "kkd_create: config is NULL"; return nullptr; }
     int n = kkd_device_count();
-    if (n <= 0) { g_createError = "kkd_create: no HIP device available (libkkdirect has no CPU fallback)"; return nullptr; }
-    if (cfg->device < 0 || cfg->device >= n) { g_createError = "kkd_create: device ordinal out of range"; return nullptr; }
+    if (n <= 0) { g_globalError = "kkd_create: no HIP device available (libkkdirect has no CPU fallback)"; return nullptr; }
+    if (cfg->device < 0 || cfg->device >= n) { g_globalError = "kkd_create: device ordinal out of range"; return nullptr; }
     hipError_t e = hipSetDevice(cfg->device);
-    if (e != hipSuccess) { g_createError = std::string("hipSetDevice: ") + hipGetErrorString(e); return nullptr; }
+    if (e != hipSuccess) { g_globalError = std::string("hipSetDevice: ") + hipGetErrorString(e); return nullptr; }
     kkd_ctx *ctx = new kkd_ctx();
     ctx->device = cfg->device; ctx->cfg = *cfg;
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { g_createError = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete ctx; return nullptr; }
-    g_createError = "";
+    if (e != hipSuccess) { g_globalError = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete ctx; return nullptr; }
+    g_globalError = "";
     return ctx;
 }
 
@@ -105,7 +104,7 @@ int kkd_probe_rfilter(int rfilter_type, float radius, const float *param2, float
     return KKD_OK;
 }
 
-const char *kkd_last_error(kkd_ctx *ctx) { return ctx ? ctx->err.c_str() : g_createError.c_str(); }
+const char *kkd_last_error(kkd_ctx *ctx) { return ctx ? ctx->err.c_str() : g_globalError.c_str(); }
 
 void kkd_request_cancel(kkd_ctx *ctx) { if (ctx) ctx->cancel.store(1); }
 

@@ -12,6 +12,9 @@
 
 namespace kkd {
 
+/* text behind kkd_last_error(NULL): the last failure of a call that has no context (kkd_create, mesh loaders) */
+extern std::string g_globalError;
+
 struct HostScene {
     BVH4 bvh;
     std::vector<uint32_t> shapeOfPrim;

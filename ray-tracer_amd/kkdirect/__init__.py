@@ -176,6 +176,73 @@ def write_npy(path, pixels):
         raise KKDError(rc, "kkd_write_npy(%s) failed" % path)
 
 
+def _mesh_to_dict(m):
+    nv, nt = int(m.n_verts), int(m.n_tris)
+
+    def arr(ptr, n, k, dt):
+        return np.ctypeslib.as_array(ptr, shape=(n * k,)).astype(dt).reshape(n, k).copy() if ptr else None
+    return {"name": m.name.decode(errors="replace"), "positions": arr(m.positions, nv, 3, np.float32), "normals": arr(m.normals, nv, 3, np.float32),
+            "texcoords": arr(m.texcoords, nv, 2, np.float32), "colors": arr(m.colors, nv, 3, np.float32),
+            "indices": arr(m.indices, nt, 3, np.uint32), "face_normals": bool(m.flags & abi.MESH_FACE_NORMALS),
+            "aabb": (np.array(m.aabb_min[:], np.float32), np.array(m.aabb_max[:], np.float32))}
+
+
+def _xf(to_world):
+    if to_world is None:
+        return None, None
+    a = np.ascontiguousarray(to_world, np.float32).reshape(16)
+    return a, a.ctypes.data_as(abi.pf32)
+
+
+def _io_check(rc, what):
+    if rc != 0:
+        raise KKDError(rc, "%s: %s" % (what, load_library().kkd_last_error(None).decode()))
+
+
+def serialized_mesh_count(path):
+    """TriMesh::readOffsetDictionary (reference src/librender/trimesh.cpp:296-337)."""
+    n = C.c_uint32(0)
+    _io_check(load_library().kkd_mesh_count_serialized(os.fsencode(path), C.byref(n)), "kkd_mesh_count_serialized")
+    return int(n.value)
+
+
+def load_serialized(path, shape_index=0, to_world=None):
+    """The serialized shape plugin (reference src/shapes/serialized.cpp:150-206) through kkd_mesh_load_serialized."""
+    lib = load_library(); m = abi.Mesh(); keep, ptr = _xf(to_world)
+    _io_check(lib.kkd_mesh_load_serialized(os.fsencode(path), shape_index, ptr, C.byref(m)), "kkd_mesh_load_serialized")
+    try:
+        return _mesh_to_dict(m)
+    finally:
+        lib.kkd_mesh_free(C.byref(m))
+
+
+def load_ply(path, to_world=None, srgb=True):
+    """The ply shape plugin (reference src/shapes/ply.cpp:96-330) through kkd_mesh_load_ply."""
+    lib = load_library(); m = abi.Mesh(); keep, ptr = _xf(to_world)
+    _io_check(lib.kkd_mesh_load_ply(os.fsencode(path), ptr, int(srgb), C.byref(m)), "kkd_mesh_load_ply")
+    try:
+        return _mesh_to_dict(m)
+    finally:
+        lib.kkd_mesh_free(C.byref(m))
+
+
+def save_serialized(path, meshes):
+    """TriMesh::serialize(Stream*) (reference src/librender/trimesh.cpp:1060-1108); meshes: dicts as load_serialized returns."""
+    lib = load_library(); arr = (abi.Mesh * len(meshes))(); keep = []
+    for k, d in enumerate(meshes):
+        m = arr[k]
+        pos = np.ascontiguousarray(d["positions"], np.float32); idx = np.ascontiguousarray(d["indices"], np.uint32); keep += [pos, idx]
+        m.n_verts, m.n_tris = len(pos), len(idx)
+        m.positions = pos.ctypes.data_as(abi.pf32); m.indices = idx.ctypes.data_as(abi.pu32)
+        for key in ("normals", "texcoords", "colors"):
+            if d.get(key) is not None:
+                a = np.ascontiguousarray(d[key], np.float32); keep.append(a)
+                setattr(m, key, a.ctypes.data_as(abi.pf32))
+        m.flags = abi.MESH_FACE_NORMALS if d.get("face_normals") else 0
+        m.name = d.get("name", "").encode()[:255]
+    _io_check(lib.kkd_mesh_save_serialized(os.fsencode(path), arr, len(meshes)), "kkd_mesh_save_serialized")
+
+
 class DirectIntegrator:
     """Host mirror of the reference's DirectIntegrator plugin (src/integrators/kk/direct.cpp:15-48).
 

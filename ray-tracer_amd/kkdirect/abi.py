@@ -87,6 +87,13 @@ class Hit(C.Structure):
 
 
 # every entry point include/kkdirect.h declares: name -> (restype, argtypes)
+class Mesh(C.Structure):
+    _fields_ = [("n_verts", u64), ("n_tris", u64), ("positions", pf32), ("normals", pf32), ("texcoords", pf32), ("colors", pf32),
+                ("indices", pu32), ("flags", u32), ("reserved", u32), ("aabb_min", f32 * 3), ("aabb_max", f32 * 3), ("name", C.c_char * 256)]
+
+
+MESH_FACE_NORMALS = 1
+
 ENTRY_POINTS = {
     "kkd_device_count": (C.c_int, []),
     "kkd_create": (C.c_void_p, [C.POINTER(Config)]),
@@ -103,6 +110,11 @@ ENTRY_POINTS = {
     "kkd_develop": (C.c_int, [C.c_void_p, pf32, u32, u32, i32, pf32]),
     "kkd_write_pfm": (C.c_int, [C.c_char_p, pf32, u32, u32, i32]),
     "kkd_write_npy": (C.c_int, [C.c_char_p, pf32, u32, u32, u32]),
+    "kkd_mesh_count_serialized": (C.c_int, [C.c_char_p, pu32]),
+    "kkd_mesh_load_serialized": (C.c_int, [C.c_char_p, i32, pf32, C.POINTER(Mesh)]),
+    "kkd_mesh_save_serialized": (C.c_int, [C.c_char_p, C.POINTER(Mesh), u32]),
+    "kkd_mesh_load_ply": (C.c_int, [C.c_char_p, pf32, i32, C.POINTER(Mesh)]),
+    "kkd_mesh_free": (None, [C.POINTER(Mesh)]),
     "kkd_request_cancel": (None, [C.c_void_p]),
     "kkd_last_error": (C.c_char_p, [C.c_void_p]),
     "kkd_destroy": (None, [C.c_void_p]),

@@ -127,6 +127,28 @@ class Scene:
             sh.emitter_id = len(self.emitters) - 1
         return sid
 
+    def add_loaded_mesh(self, mesh, material, face_normals=None, flip_normals=False, **kw):
+        """A mesh dict from kkdirect.load_serialized / load_ply, configured like TriMesh::configure (reference
+        src/librender/trimesh.cpp:366-390): stored normals are used unless faceNormals is set; a mesh without normals gets
+        smooth vertex normals (computeNormals); flipNormals negates them."""
+        fn = mesh["face_normals"] if face_normals is None else face_normals
+        nrm = None
+        if not fn:
+            nrm = mesh["normals"] if mesh["normals"] is not None else compute_vertex_normals(mesh["positions"], mesh["indices"])
+            if flip_normals:
+                nrm = -nrm
+        return self.add_mesh(mesh["positions"], mesh["indices"], material, normals=nrm, texcoords=mesh["texcoords"], **kw)
+
+    def add_serialized(self, path, material, shape_index=0, to_world=None, face_normals=None, flip_normals=False, **kw):
+        """<shape type="serialized"> (reference src/shapes/serialized.cpp:150-206)."""
+        from . import load_serialized
+        return self.add_loaded_mesh(load_serialized(path, shape_index, to_world), material, face_normals, flip_normals, **kw)
+
+    def add_ply(self, path, material, to_world=None, srgb=True, face_normals=None, flip_normals=False, **kw):
+        """<shape type="ply"> (reference src/shapes/ply.cpp:96-136)."""
+        from . import load_ply
+        return self.add_loaded_mesh(load_ply(path, to_world, srgb), material, face_normals, flip_normals, **kw)
+
     def add_point_light(self, position, intensity, sampling_weight=1.0):
         e = abi.Emitter()
         e.type = abi.EMITTER_POINT; e.shape_id = -1; e.sampling_weight = sampling_weight

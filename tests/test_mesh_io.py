@@ -1,0 +1,237 @@
+"""On-disk mesh formats (the step right before the path).  CPU tests: the host-only loaders behind the
+C ABI against the oracle's Python restatement of TriMesh::loadCompressed / serialize and PLYLoader, on files generated
+here (the reference ships no mesh files: data/tests/*.ply are absent).  GPU test: a scene assembled from files
+renders the same image as the scene assembled from arrays."""
+import struct
+import numpy as np
+import pytest
+import kkoracle
+import kkdirect
+from kkdirect import Scene, scenes, look_at
+
+KEYS = ("positions", "normals", "texcoords", "colors", "indices")
+
+
+def _mesh(seed, n=9, normals=True, uv=True, colors=False, name="mesh"):
+    rng = np.random.RandomState(seed)
+    xs = np.linspace(-1, 1, n, dtype=np.float32)
+    X, Z = np.meshgrid(xs, xs, indexing="ij")
+    pos = np.stack([X, 0.2 * np.sin(3 * X + seed) * np.cos(2 * Z), Z], -1).reshape(-1, 3).astype(np.float32)
+    idx = scenes._grid(n - 1, n - 1)
+    m = {"name": name, "positions": pos, "indices": idx, "normals": None, "texcoords": None, "colors": None, "face_normals": False}
+    if normals:
+        nr = rng.normal(size=pos.shape).astype(np.float32); m["normals"] = nr / np.linalg.norm(nr, axis=1, keepdims=True).astype(np.float32)
+    if uv:
+        m["texcoords"] = rng.rand(len(pos), 2).astype(np.float32)
+    if colors:
+        m["colors"] = rng.rand(len(pos), 3).astype(np.float32)
+    return m
+
+
+def _same(a, b, exact=True):
+    for k in KEYS:
+        assert (a[k] is None) == (b[k] is None), k
+        if a[k] is not None:
+            if (exact and k != "colors") or k == "indices":      # colours pass through pow(): library-dependent last bit
+                assert np.array_equal(a[k], b[k]), k
+            else:
+                np.testing.assert_allclose(a[k], b[k], rtol=2e-6, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("version,double", [(4, False), (4, True), (3, False), (3, True)])
+def test_serialized_load_matches_oracle(tmp_path, version, double):
+    meshes = [_mesh(1, name="first"), _mesh(2, n=5, normals=False, uv=False, colors=True, name="second"), _mesh(3, n=7, uv=False, name="third")]
+    meshes[2]["face_normals"] = True
+    path = str(tmp_path / "m.serialized")
+    kkoracle.save_serialized(path, meshes, version=version, double=double)
+    assert kkdirect.serialized_mesh_count(path) == 3
+    for i, src in enumerate(meshes):
+        got = kkdirect.load_serialized(path, i)
+        ref = kkoracle.load_serialized(path, i)
+        _same(got, ref)
+        _same(got, src, exact=True)              # float32 -> float64 -> float32 is lossless
+        assert got["face_normals"] == src["face_normals"]
+        assert got["name"] == (src["name"] if version == 4 else "")
+        assert np.array_equal(got["aabb"][0], src["positions"].min(0)) and np.array_equal(got["aabb"][1], src["positions"].max(0))
+
+
+def test_serialized_single_mesh_without_dictionary(tmp_path):
+    path = str(tmp_path / "one.serialized")
+    kkoracle.save_serialized(path, [_mesh(4)], dictionary=False)
+    assert kkdirect.serialized_mesh_count(path) == 1
+    _same(kkdirect.load_serialized(path, 0), kkoracle.load_serialized(path, 0))
+    with pytest.raises(kkdirect.KKDError):
+        kkdirect.load_serialized(path, 1)
+
+
+def test_serialized_to_world_and_mirroring(tmp_path):
+    path = str(tmp_path / "m.serialized")
+    kkoracle.save_serialized(path, [_mesh(5)])
+    rot = look_at((1, 2, 3), (0, 0.5, 0), (0, 1, 0)).astype(np.float32)
+    rot[:3, :3] *= np.float32(1.7)
+    mirror = np.diag([-1, 1, 1, 1]).astype(np.float32) @ rot
+    for tw in (rot, mirror, np.eye(4, dtype=np.float32)):
+        got = kkdirect.load_serialized(path, 0, tw)
+        ref = kkoracle.load_serialized(path, 0, tw)
+        _same(got, ref, exact=False)
+    flipped = kkdirect.load_serialized(path, 0, mirror)["indices"]
+    plain = kkdirect.load_serialized(path, 0, rot)["indices"]
+    assert np.array_equal(flipped[:, [1, 0, 2]], plain)          # det < 0: idx[0] <-> idx[1], serialized.cpp:196-201
+
+
+def test_serialized_writer_roundtrip_and_oracle_reads_it(tmp_path):
+    meshes = [_mesh(6, colors=True, name="a"), _mesh(7, n=4, normals=False, name="b")]
+    path = str(tmp_path / "w.serialized")
+    kkdirect.save_serialized(path, meshes)
+    raw = open(path, "rb").read()
+    assert struct.unpack_from("<HH", raw, 0) == (0x041C, 4) and struct.unpack_from("<I", raw, len(raw) - 4)[0] == 2
+    for i, src in enumerate(meshes):
+        _same(kkoracle.load_serialized(path, i), src)
+        _same(kkdirect.load_serialized(path, i), src)
+        assert kkoracle.load_serialized(path, i)["name"] == src["name"]
+
+
+def test_serialized_errors(tmp_path):
+    bad = tmp_path / "bad.serialized"
+    bad.write_bytes(b"\x04\x1c\x04\x00" + b"\0" * 64)            # the byte-swapped header of old files, trimesh.cpp:253-257
+    with pytest.raises(kkdirect.KKDError, match="old version"):
+        kkdirect.load_serialized(str(bad))
+    bad.write_bytes(b"\x1c\x04\x09\x00" + b"\0" * 64)
+    with pytest.raises(kkdirect.KKDError, match="incompatible"):
+        kkdirect.load_serialized(str(bad))
+    good = str(tmp_path / "g.serialized")
+    kkoracle.save_serialized(good, [_mesh(8)])
+    raw = open(good, "rb").read()
+    (tmp_path / "trunc.serialized").write_bytes(raw[:len(raw) // 2])
+    with pytest.raises(kkdirect.KKDError):
+        kkdirect.load_serialized(str(tmp_path / "trunc.serialized"))
+    with pytest.raises(kkdirect.KKDError):
+        kkdirect.load_serialized(str(tmp_path / "missing.serialized"))
+    with pytest.raises(kkdirect.KKDError):
+        kkdirect.load_serialized(good, 5)
+
+
+def _write_ply(path, mode, mesh, quads=False, color_type="uchar", count_type="uchar", index_type="int", extra=True):
+    pos, nrm, uv = mesh["positions"], mesh["normals"], mesh["texcoords"]
+    nv = len(pos)
+    faces = [list(t) for t in mesh["indices"]]
+    if quads:   # merge pairs of grid triangles (a, b, c) + (d, a, c) back into quads (a, b, c, d)
+        faces = [[0, 1, 2, 3], [4, 5, 6]] + faces[2:]
+    cols = (np.random.RandomState(9).rand(nv, 3) * 255).astype(np.uint8)
+    props = ["property float x", "property float y", "property float z"]
+    if extra:
+        props.append("property double confidence")      # parsed and dropped: no float64 callback
+    if nrm is not None:
+        props += ["property float nx", "property float ny", "property float nz"]
+    if uv is not None:
+        props += ["property float s", "property float t"]
+    props += ["property %s red" % color_type, "property %s green" % color_type, "property %s blue" % color_type]
+    fmt = {"ascii": "ascii", "le": "binary_little_endian", "be": "binary_big_endian"}[mode]
+    head = ["ply", "format %s 1.0" % fmt, "comment made by tests", "element vertex %d" % nv] + props + \
+           ["element face %d" % len(faces), "property list %s %s vertex_indices" % (count_type, index_type), "property uchar flags",
+            "element edge 1", "property int a", "property int b", "end_header"]
+    bo = ">" if mode == "be" else "<"
+    tp = {"uchar": "u1", "float": "f4", "int": "i4", "uint": "u4"}
+    with open(path, "wb") as f:
+        f.write(("\n".join(head) + "\n").encode())
+        for v in range(nv):
+            vals = [(pos[v, 0], "f4"), (pos[v, 1], "f4"), (pos[v, 2], "f4")]
+            if extra:
+                vals.append((0.5, "f8"))
+            if nrm is not None:
+                vals += [(nrm[v, k], "f4") for k in range(3)]
+            if uv is not None:
+                vals += [(uv[v, k], "f4") for k in range(2)]
+            vals += [((cols[v, k] if color_type == "uchar" else cols[v, k] / 255.0), tp[color_type]) for k in range(3)]
+            if mode == "ascii":
+                f.write((" ".join(repr(float(x)) if t[0] == "f" else str(int(x)) for x, t in vals) + "\n").encode())
+            else:
+                for x, t in vals:
+                    f.write(np.array([x], bo + t).tobytes())
+        for fc in faces:
+            if mode == "ascii":
+                f.write(("%d %s 7\n" % (len(fc), " ".join(str(i) for i in fc))).encode())
+            else:
+                f.write(np.array([len(fc)], bo + tp[count_type]).tobytes() + np.array(fc, bo + tp[index_type]).tobytes() + b"\x07")
+        f.write(b"3 4\n" if mode == "ascii" else np.array([3, 4], bo + "i4").tobytes())
+
+
+@pytest.mark.parametrize("mode", ["ascii", "le", "be"])
+@pytest.mark.parametrize("variant", [dict(), dict(quads=True, count_type="uint", index_type="uint"), dict(color_type="float", extra=False)])
+def test_ply_load_matches_oracle(tmp_path, mode, variant):
+    mesh = _mesh(11, n=6)
+    path = str(tmp_path / "bunny.ply")
+    _write_ply(path, mode, mesh, **variant)
+    tw = look_at((0, 1, 4), (0, 0, 0), (0, 1, 0)).astype(np.float32)
+    for to_world in (None, tw):
+        for srgb in (True, False):
+            got = kkdirect.load_ply(path, to_world, srgb)
+            ref = kkoracle.load_ply(path, to_world, srgb)
+            _same(got, ref, exact=(to_world is None and mode != "ascii"))
+            assert got["name"] == "bunny" and got["colors"] is not None
+    got = kkdirect.load_ply(path)
+    if variant.get("quads"):
+        assert np.array_equal(got["indices"][:3], [[0, 1, 2], [3, 0, 2], [4, 5, 6]])          # ply.cpp:296-306
+    else:
+        assert np.array_equal(got["indices"], mesh["indices"])
+    if mode != "ascii":
+        assert np.array_equal(got["positions"], mesh["positions"]) and np.array_equal(got["texcoords"], mesh["texcoords"])
+
+
+def test_ply_errors(tmp_path):
+    mesh = _mesh(12, n=4)
+    p = str(tmp_path / "m.ply")
+    _write_ply(p, "le", mesh)
+    raw = open(p, "rb").read()
+    (tmp_path / "trunc.ply").write_bytes(raw[:-40])
+    with pytest.raises(kkdirect.KKDError):
+        kkdirect.load_ply(str(tmp_path / "trunc.ply"))
+    (tmp_path / "notply.ply").write_bytes(b"solid\n")
+    with pytest.raises(kkdirect.KKDError):
+        kkdirect.load_ply(str(tmp_path / "notply.ply"))
+    # double-precision positions have no callback in the reference loader: nothing is stored, the load fails on purpose? no:
+    # positions stay zero but faces load; pentagons are rejected
+    (tmp_path / "penta.ply").write_bytes(b"ply\nformat ascii 1.0\nelement vertex 5\nproperty float x\nproperty float y\nproperty float z\n"
+                                         b"element face 1\nproperty list uchar int vertex_indices\nend_header\n"
+                                         b"0 0 0\n1 0 0\n1 1 0\n0 1 0\n0.5 2 0\n5 0 1 2 3 4\n")
+    with pytest.raises(kkdirect.KKDError, match="triangle and quad"):
+        kkdirect.load_ply(str(tmp_path / "penta.ply"))
+
+
+def test_scene_from_files_equals_scene_from_arrays(tmp_path):
+    a = _mesh(13, n=12, normals=False, uv=False)
+    b = _mesh(14, n=6, normals=True, uv=True)
+    kkdirect.save_serialized(str(tmp_path / "s.serialized"), [a, b])
+    _write_ply(str(tmp_path / "p.ply"), "le", b)
+    s1 = Scene(); m = s1.diffuse()
+    s1.add_serialized(str(tmp_path / "s.serialized"), m, shape_index=0)
+    s1.add_ply(str(tmp_path / "p.ply"), m)
+    s2 = Scene(); m = s2.diffuse()
+    s2.add_mesh(a["positions"], a["indices"], m, normals=kkdirect.compute_vertex_normals(a["positions"], a["indices"]))
+    s2.add_mesh(b["positions"], b["indices"], m, normals=b["normals"], texcoords=b["texcoords"])
+    for x, y in zip(s1.arrays(), s2.arrays()):
+        # the ply loader re-normalises stored normals (ply.cpp:229): last-bit differences against the raw arrays
+        assert (x is None) == (y is None) and (x is None or np.allclose(x, y, rtol=0, atol=2e-7))
+
+
+@pytest.mark.gpu
+def test_render_scene_loaded_from_files(gpu, tmp_path):
+    cb = scenes.cornell_box(64, 64)
+    pos, idx = cb.arrays()[:2]
+    ground = _mesh(15, n=20, normals=False, uv=False)
+    ground["positions"] = (ground["positions"] * np.float32(120) + np.float32([278, 60, 280])).astype(np.float32)
+    kkdirect.save_serialized(str(tmp_path / "g.serialized"), [ground])
+
+    def build(from_file):
+        sc = scenes.cornell_box(64, 64)
+        m = sc.diffuse((0.3, 0.5, 0.7))
+        if from_file:
+            sc.add_serialized(str(tmp_path / "g.serialized"), m)
+        else:
+            sc.add_mesh(ground["positions"], ground["indices"], m, normals=kkdirect.compute_vertex_normals(ground["positions"], ground["indices"]))
+        return sc
+    with gpu.Context(device=0).upload(build(True)) as c1, gpu.Context(device=0).upload(build(False)) as c2:
+        f1, _ = c1.render(8)
+        f2, _ = c2.render(8)
+    # same samples, same scene; float atomics of neighbouring footprints commute only up to rounding
+    assert f1[..., 4].sum() > 0 and np.allclose(f1, f2, rtol=1e-4, atol=1e-4)
