@@ -182,7 +182,15 @@ typedef struct kkd_render_params {
     uint32_t block_size;       /* tile edge in pixels, 0 = 32 (scene.cpp:24)                   */
     uint32_t tile_index, tile_count;  /* 0,1 (or 0,0) = all tiles                              */
     uint32_t sample_first;     /* first RNG sample index (0)                                   */
+    /* which Li: KKD_INTEGRATOR_KK = the path of this library, DirectIntegrator::Li (src/integrators/kk/direct.cpp:50-178);
+     * KKD_INTEGRATOR_DIRECT = its sibling on the same kernels, MIDirectIntegrator::Li of the stock 'direct' plugin
+     * (src/integrators/direct/direct.cpp:147-311): emitter samples first, power heuristic, 'strictNormals'; there
+     * light_samples is 'emitterSamples' and one of the two counts may be 0. */
+    uint32_t integrator;
+    int32_t  strict_normals;   /* 'strictNormals' of the direct plugin (direct.cpp:103); ignored by KKD_INTEGRATOR_KK */
 } kkd_render_params;
+#define KKD_INTEGRATOR_KK     0u
+#define KKD_INTEGRATOR_DIRECT 1u
 
 /* ray classes / kernel stages of one render (indices of the arrays in kkd_stats) */
 #define KKD_RAYS_PRIMARY 0   /* sensor rays, closest hit   (kernel kPrimary)                      */

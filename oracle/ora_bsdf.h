@@ -30,7 +30,8 @@ enum {
     EDiffuseReflection = 0x0004, EGlossyReflection = 0x0010, EDeltaReflection = 0x0040,
     EDeltaTransmission = 0x0080, EFrontSide = 0x1000, EBackSide = 0x2000,
     EDelta = EDeltaReflection | EDeltaTransmission,
-    ETransmission = EDeltaTransmission
+    ETransmission = EDeltaTransmission,
+    ESmooth = EDiffuseReflection | 0x0008 /* EDiffuseTransmission */ | EGlossyReflection | 0x0020 /* EGlossyTransmission */
 };
 
 /* ---- bsdfs/microfacet.h ------------------------------------------------------------------- */

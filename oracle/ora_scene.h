@@ -342,7 +342,8 @@ struct Sensor {
     }
 };
 
-struct RenderParams { uint32_t spp, nB, nL; bool hideEmitters; uint32_t blockSize, tileIndex, tileCount, sampleFirst; uint64_t seed; };
+struct RenderParams { uint32_t spp, nB, nL; bool hideEmitters; uint32_t blockSize, tileIndex, tileCount, sampleFirst; uint64_t seed;
+                      uint32_t integrator = 0; bool strictNormals = false; };
 struct Stats { std::atomic<uint64_t> samples{0}, raysClosest{0}, raysShadow{0}, nodes{0}, tris{0}; };
 
 class Scene {
@@ -390,6 +391,7 @@ public:
 
     /* ---- integrator ---- */
     V3 Li(const Ray &ray, SampleStream &rng, const RenderParams &rp, Float &alpha, Stats *st) const;
+    V3 LiDirectPlugin(const Ray &ray, const Intersection &its, int bsdf, uint32_t btype, V3 refN, SampleStream &rng, const RenderParams &rp, Stats *st) const;
     void render(const RenderParams &rp, float *film, Stats *st, int nThreads) const;
 };
 
@@ -527,6 +529,8 @@ inline V3 Scene::Li(const Ray &ray, SampleStream &rng, const RenderParams &rp, F
     const uint32_t btype = bsdfs.getType(bsdf);
     V3 refN = (btype & (ETransmission | EBackSide)) ? V3(0.f) : its.shFrame.n;
 
+    if (rp.integrator == KKD_INTEGRATOR_DIRECT) return L + LiDirectPlugin(ray, its, bsdf, btype, refN, rng, rp, st);
+
     std::vector<SV> brdfSamples, lightSamples;
     /* integrateBrdf :74-125 */
     for (uint32_t i = 0; i < rp.nB; ++i) {
@@ -581,6 +585,58 @@ inline V3 Scene::Li(const Ray &ray, SampleStream &rng, const RenderParams &rp, F
     for (const SV &s : lightSamples) {
         Float weight = cLight * s.pdf / (cBrdf * s.otherPdf + cLight * s.pdf);
         L += weight * s.value * s.bsdfValue * lightFrag;
+    }
+    return L;
+}
+
+/* MIDirectIntegrator::Li after the emitted-radiance terms (reference src/integrators/direct/direct.cpp:176-311, depth 1,
+ * no adaptive query): emitter sampling first, then BSDF sampling, power heuristic with the sample-count fractions. */
+inline V3 Scene::LiDirectPlugin(const Ray &ray, const Intersection &its, int bsdf, uint32_t btype, V3 refN, SampleStream &rng,
+                                const RenderParams &rp, Stats *st) const {
+    V3 L(0.f);
+    if (rp.strictNormals && dot(ray.d, its.geoFrame.n) * its.wi.z >= 0) return L;      /* :177-190 */
+    const Float sum = (Float)(rp.nB + rp.nL);
+    const Float weightBSDF = 1 / (Float)rp.nB, weightLum = 1 / (Float)rp.nL, fracBSDF = rp.nB / sum, fracLum = rp.nL / sum;   /* :129-136 */
+    auto miWeight = [](Float a, Float b) { a *= a; b *= b; return a / (a + b); };        /* :313-316 */
+    DirectRec dRec; dRec.ref = its.p; dRec.refN = refN;
+    for (uint32_t i = 0; i < rp.nL; ++i) {                                               /* :219-250 */
+        V2 u = rng.next2D();
+        if (!(btype & ESmooth)) continue;
+        V3 value = sampleEmitterDirect(dRec, u, st);
+        if (isZero(value)) continue;
+        const EmitterRec &e = emitters[dRec.emitter];
+        V3 woLocal = its.toLocal(dRec.d);
+        const V3 bsdfVal = bsdfs.eval(bsdf, its.wi, woLocal);
+        if (!isZero(bsdfVal) && (!rp.strictNormals || dot(its.geoFrame.n, dRec.d) * woLocal.z > 0)) {
+            Float bsdfPdf = (e.type != KKD_EMITTER_POINT) ? bsdfs.pdf(bsdf, its.wi, woLocal) : 0;
+            const Float weight = miWeight(dRec.pdf * fracLum, bsdfPdf * fracBSDF) * weightLum;
+            L += value * bsdfVal * weight;
+        }
+    }
+    for (uint32_t i = 0; i < rp.nB; ++i) {                                               /* :256-309 */
+        V2 u = rng.next2D();
+        V3 woLocal; Float bsdfPdf; uint32_t sampledType;
+        V3 bsdfVal = bsdfs.sample(bsdf, its.wi, u, woLocal, bsdfPdf, sampledType);
+        if (isZero(bsdfVal)) continue;
+        const V3 wo = its.toWorld(woLocal);
+        if (rp.strictNormals && dot(its.geoFrame.n, wo) * woLocal.z <= 0) continue;
+        Ray bsdfRay(its.p, wo, kEpsilon, std::numeric_limits<Float>::infinity());
+        DirectRec bRec; bRec.ref = its.p; bRec.refN = refN;
+        V3 value; Hit bh;
+        if (rayIntersect(bsdfRay, bh, st)) {
+            Intersection bIts; fillIntersection(bsdfRay, bh, bIts);
+            const ShapeRec &bs = shapes[bIts.shape];
+            if (bs.emitter < 0) continue;
+            value = emitterEvalArea(emitters[bs.emitter], bIts, -bsdfRay.d);
+            bRec.p = bIts.p; bRec.n = bIts.shFrame.n; bRec.d = bsdfRay.d; bRec.dist = bIts.t; bRec.measure = 0; bRec.emitter = bs.emitter;
+        } else {
+            if (envEmitter < 0) continue;        /* sampledType == ENull does not occur with the BSDFs of this path */
+            value = env.evalEnvironment(bsdfRay.d);
+            if (!envFillDirectRec(bRec, bsdfRay)) continue;
+        }
+        const Float lumPdf = !(sampledType & EDelta) ? pdfEmitterDirect(bRec) : 0;
+        const Float weight = miWeight(bsdfPdf * fracBSDF, lumPdf * fracLum) * weightBSDF;
+        L += value * bsdfVal * weight;
     }
     return L;
 }

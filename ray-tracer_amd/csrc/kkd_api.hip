@@ -320,7 +320,11 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     if (!rp) return fail(ctx, KKD_ERR_INVALID, "render params are NULL");
     if (rp->spp == 0) return fail(ctx, KKD_ERR_INVALID, "spp must be positive");
     /* kk/direct.cpp:165-166 divides by both counts: zero is not a meaningful configuration */
-    if (rp->bsdf_samples == 0 || rp->light_samples == 0) return fail(ctx, KKD_ERR_UNSUPPORTED, "bsdfSamples and lightSamples must be >= 1");
+    if (rp->integrator > KKD_INTEGRATOR_DIRECT) return fail(ctx, KKD_ERR_INVALID, "unknown integrator");
+    if (rp->integrator == KKD_INTEGRATOR_KK && (rp->bsdf_samples == 0 || rp->light_samples == 0))
+        return fail(ctx, KKD_ERR_UNSUPPORTED, "bsdfSamples and lightSamples must be >= 1");
+    /* the stock plugin only asserts emitterSamples + bsdfSamples > 0 (integrators/direct/direct.cpp:107) */
+    if (rp->bsdf_samples + rp->light_samples == 0) return fail(ctx, KKD_ERR_INVALID, "emitterSamples + bsdfSamples must be > 0");
     if (rp->bsdf_samples > 64 || rp->light_samples > 64) return fail(ctx, KKD_ERR_UNSUPPORTED, "bsdfSamples / lightSamples above 64");
     const uint32_t bs = rp->block_size ? rp->block_size : 32;                    /* scene.cpp:24 */
     if (bs < 2 || bs > 128) return fail(ctx, KKD_ERR_INVALID, "block size must be in [2, 128]");   /* mitsuba.cpp:142 */
@@ -364,6 +368,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     bp.seed = ctx->cfg.seed; bp.stride = (uint32_t)S;
     bp.g = g; bp.gShift = gShift; bp.chunks = chunks; bp.spp = rp->spp; bp.sampleFirst = rp->sample_first;
     bp.nB = nB; bp.nL = nL; bp.hideEmitters = rp->hide_emitters != 0;
+    bp.integrator = rp->integrator; bp.strictNormals = rp->strict_normals != 0;
     bp.bs = bs; bp.bsPow2 = (bs & (bs - 1)) == 0; bp.nbx = nbx; bp.nby = nby;
     bp.tileIndex = tileIndex; bp.tileCount = tileCount; bp.nTilesMine = nTilesMine; bp.W = W; bp.H = H;
     { const char *dbg = getenv("KKD_DEBUG"); bp.debug = dbg ? (uint32_t)atoi(dbg) : 0u; }

@@ -20,6 +20,7 @@ struct BatchParams {
     uint32_t count, stride;          /* stride: element pitch between the per-sample planes of multi-sample buffers */
     uint32_t g, gShift, chunks, spp, sampleFirst;
     uint32_t nB, nL, hideEmitters;
+    uint32_t integrator, strictNormals;   /* KKD_INTEGRATOR_*; 'strictNormals' of the stock direct plugin */
     uint32_t bs, bsPow2, nbx, nby, tileIndex, tileCount, nTilesMine;
     int32_t W, H;
     uint32_t debug;                  /* developer ablation bits from $KKD_DEBUG: 1 = no film atomics, 2 = no BSDF-hit evaluation */

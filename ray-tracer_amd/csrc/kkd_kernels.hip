@@ -153,17 +153,23 @@ __global__ void __launch_bounds__(256, 4) kShade(DScene sc, BatchParams bp, Wave
     const uint32_t btype = sc.materials[its.material].typeFlags;
     const f3 refN = (btype & (ETransmission | EBackSide)) ? f3(0.f) : its.sh.n;   /* DirectSamplingRecord(its) */
     const float cB = nB / (float)(nB + nL), cL = nL / (float)(nB + nL);            /* :163-166 */
+    /* sibling integrator on the same kernels: MIDirectIntegrator::Li (integrators/direct/direct.cpp:176-311) draws the
+     * emitter samples before the BSDF samples, applies the geometric-normal tests only with 'strictNormals', samples
+     * emitters only for smooth BSDFs and weights with the power heuristic */
+    const bool stock = bp.integrator == KKD_INTEGRATOR_DIRECT;
+    const bool geoTest = !stock || bp.strictNormals;
+    const bool dead = stock && bp.strictNormals && dot(its.geoN, rd) * its.wi.z >= 0.f;   /* direct.cpp:177-190 */
 
     /* integrateBrdf :74-104 -- the part before the ray is traced */
     for (uint32_t b = 0; b < nB; ++b) {
-        const f2 u = sample2D(bp.seed, s.pixel, s.sample, 2u + 2u * b);
+        const f2 u = sample2D(bp.seed, s.pixel, s.sample, 2u + 2u * b + (stock ? 2u * nL : 0u));
         f3 woLocal; float bsdfPdf; uint32_t sampledType;
         const f3 bsdfVal = sampleBsdf(sc, its.material, its.wi, u, woLocal, bsdfPdf, sampledType);
         DRay r; killRay(r);
         float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!isZero(bsdfVal)) {
+        if (!isZero(bsdfVal) && !dead) {
             const f3 wo = its.sh.toWorld(woLocal);
-            if (dot(its.geoN, wo) * woLocal.z > 0.f) {               /* :96-99 */
+            if (!geoTest || dot(its.geoN, wo) * woLocal.z > 0.f) {   /* :96-99; direct.cpp:267-271 */
                 r.ox = its.p.x; r.oy = its.p.y; r.oz = its.p.z; r.mint = kEpsilon;
                 r.dx = wo.x; r.dy = wo.y; r.dz = wo.z; r.maxt = kInf;
                 rec = make_float4(bsdfVal.x, bsdfVal.y, bsdfVal.z, (sampledType & EDelta) ? -bsdfPdf : bsdfPdf);
@@ -178,17 +184,18 @@ __global__ void __launch_bounds__(256, 4) kShade(DScene sc, BatchParams bp, Wave
     for (uint32_t l = 0; l < nL; ++l) {
         DRay r; killRay(r);
         float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (btype && sc.nEmitters) {                                 /* :140 */
-            const f2 u = sample2D(bp.seed, s.pixel, s.sample, 2u + 2u * nB + 2u * l);
+        if ((stock ? (btype & ESmooth) != 0u && !dead : btype != 0u) && sc.nEmitters) {      /* :140; direct.cpp:215 */
+            const f2 u = sample2D(bp.seed, s.pixel, s.sample, 2u + 2u * l + (stock ? 0u : 2u * nB));
             DirectRec dRec; dRec.ref = its.p; dRec.refN = refN; dRec.emitter = -1;
             const f3 value = sampleEmitterDirectUnoccluded(sc, dRec, u);
             if (!isZero(value)) {
                 const f3 woLocal = its.sh.toLocal(dRec.d);
                 const f3 bsdfVal = evalBsdf(sc, its.material, its.wi, woLocal);
-                if (!isZero(bsdfVal) && dot(its.geoN, dRec.d) * woLocal.z > 0.f) {   /* :154 */
+                if (!isZero(bsdfVal) && (!geoTest || dot(its.geoN, dRec.d) * woLocal.z > 0.f)) {   /* :154; direct.cpp:233-234 */
                     const bool onSurface = sc.emitters[dRec.emitter].type != KKD_EMITTER_POINT;
                     const float bsdfPdf = onSurface ? pdfBsdf(sc, its.material, its.wi, woLocal) : 0.f;
-                    const float weight = cL * dRec.pdf / (cB * bsdfPdf + cL * dRec.pdf);
+                    const float pa = cL * dRec.pdf, pb = cB * bsdfPdf;
+                    const float weight = stock ? (pa * pa) / (pa * pa + pb * pb) : pa / (pb + pa);   /* direct.cpp:241-243, 313-316 */
                     const f3 contrib = value * bsdfVal * (weight / (float)nL);
                     rec = make_float4(contrib.x, contrib.y, contrib.z, 0.f);
                     r.ox = its.p.x; r.oy = its.p.y; r.oz = its.p.z; r.mint = kEpsilon;   /* scene.cpp:840-841 */
@@ -309,7 +316,8 @@ __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveB
             }
             const float bsdfPdf = fabsf(rec.w);
             const float lightPdf = rec.w > 0.f ? pdfEmitterDirect(sc, dRec) : 0.f;
-            const float weight = cB * bsdfPdf / (cB * bsdfPdf + cL * lightPdf);
+            const float pa = cB * bsdfPdf, pb = cL * lightPdf;
+            const float weight = bp.integrator == KKD_INTEGRATOR_DIRECT ? (pa * pa) / (pa * pa + pb * pb) : pa / (pa + pb);   /* direct.cpp:303-305 */
             L += value * f3(rec.x, rec.y, rec.z) * (weight / (float)nB);
         }
         for (uint32_t l = 0; l < nL; ++l) {

@@ -58,7 +58,8 @@ struct alignas(16) ProjTri {
 enum : uint32_t {
     EDiffuseReflection = 0x0004, EGlossyReflection = 0x0010, EDeltaReflection = 0x0040,
     EDeltaTransmission = 0x0080, EFrontSide = 0x1000, EBackSide = 0x2000,
-    EDelta = EDeltaReflection | EDeltaTransmission, ETransmission = EDeltaTransmission
+    EDelta = EDeltaReflection | EDeltaTransmission, ETransmission = EDeltaTransmission,
+    ESmooth = EDiffuseReflection | 0x0008 /* EDiffuseTransmission */ | EGlossyReflection | 0x0020 /* EGlossyTransmission */
 };
 
 struct DMaterial {          /* 128 bytes */

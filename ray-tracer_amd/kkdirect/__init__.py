@@ -90,22 +90,26 @@ class Context:
         return dict(node_bytes=nb.value, tri_bytes=tb.value, n_nodes=nn.value, n_leaf_tris=nt.value)
 
     @staticmethod
-    def _params(spp, bsdf_samples, light_samples, hide_emitters, block_size, tile_index, tile_count, sample_first):
-        return abi.RenderParams(spp, bsdf_samples, light_samples, int(hide_emitters), block_size, tile_index, tile_count, sample_first)
+    def _params(spp, bsdf_samples, light_samples, hide_emitters, block_size, tile_index, tile_count, sample_first,
+                integrator=abi.INTEGRATOR_KK, strict_normals=False):
+        return abi.RenderParams(spp, bsdf_samples, light_samples, int(hide_emitters), block_size, tile_index, tile_count, sample_first,
+                                integrator, int(strict_normals))
 
     def render(self, spp, bsdf_samples=1, light_samples=1, hide_emitters=False, block_size=0, tile_index=0, tile_count=1,
-               sample_first=0):
+               sample_first=0, integrator=abi.INTEGRATOR_KK, strict_normals=False):
         """-> (film[H, W, 5] float32 = {R*w, G*w, B*w, alpha*w, w}, abi.Stats)"""
-        p = self._params(spp, bsdf_samples, light_samples, hide_emitters, block_size, tile_index, tile_count, sample_first)
+        p = self._params(spp, bsdf_samples, light_samples, hide_emitters, block_size, tile_index, tile_count, sample_first,
+                         integrator, strict_normals)
         film = np.zeros((self.height, self.width, 5), np.float32)
         st = abi.Stats()
         self._check(self.lib.kkd_render(self.h, C.byref(p), film.ctypes.data_as(abi.pf32), C.byref(st)))
         return film, st
 
     def render_device(self, dev_ptr, spp, bsdf_samples=1, light_samples=1, hide_emitters=False, block_size=0, tile_index=0,
-                      tile_count=1, sample_first=0):
+                      tile_count=1, sample_first=0, integrator=abi.INTEGRATOR_KK, strict_normals=False):
         """Render into caller-owned device memory (H*W*5 floats, e.g. tensor.data_ptr()); -> abi.Stats"""
-        p = self._params(spp, bsdf_samples, light_samples, hide_emitters, block_size, tile_index, tile_count, sample_first)
+        p = self._params(spp, bsdf_samples, light_samples, hide_emitters, block_size, tile_index, tile_count, sample_first,
+                         integrator, strict_normals)
         st = abi.Stats()
         self._check(self.lib.kkd_render_device(self.h, C.byref(p), C.c_void_p(dev_ptr), C.byref(st)))
         return st
@@ -289,3 +293,45 @@ class DirectIntegrator:
         """SamplingIntegrator::cancel (reference src/librender/integrator.cpp:90-93)."""
         for c in list(self._cancel_targets):
             c.request_cancel()
+
+
+class MIDirectIntegrator:
+    """Host mirror of the stock 'direct' plugin (reference src/integrators/direct/direct.cpp:91-146), a sibling of the kk
+    integrator that runs on the same kernels: shadingSamples / emitterSamples / bsdfSamples /
+    strictNormals / hideEmitters, power heuristic."""
+    PLUGIN_NAME = "direct"
+    DESCRIPTION = "Direct illumination integrator"
+
+    def __init__(self, props=None, **kw):
+        props = dict(props or {}, **kw)
+        shading = int(props.pop("shadingSamples", 1))
+        self.emitterSamples = int(props.pop("emitterSamples", shading))
+        self.bsdfSamples = int(props.pop("bsdfSamples", shading))
+        self.strictNormals = bool(props.pop("strictNormals", False))
+        self.hideEmitters = bool(props.pop("hideEmitters", False))
+        if props:
+            raise ValueError("direct: unreferenced properties %s" % sorted(props))
+        if self.emitterSamples < 0 or self.bsdfSamples < 0 or self.emitterSamples + self.bsdfSamples <= 0:
+            raise ValueError("direct: emitterSamples + bsdfSamples must be > 0")     # Assert, direct.cpp:107
+
+    def serialize(self):
+        """Field order of MIDirectIntegrator::serialize (direct/direct.cpp:120-126): size, size, bool, bool."""
+        import struct
+        return struct.pack("<QQ??", self.emitterSamples, self.bsdfSamples, self.strictNormals, self.hideEmitters)
+
+    @classmethod
+    def unserialize(cls, blob):
+        import struct
+        e, b, s, h = struct.unpack("<QQ??", blob)
+        return cls(emitterSamples=e, bsdfSamples=b, strictNormals=s, hideEmitters=h)
+
+    def render(self, scene, spp, device=0, seed=1, ctx=None, **kw):
+        own = ctx is None
+        if own:
+            ctx = Context(device=device, seed=seed).upload(scene)
+        try:
+            return ctx.render(spp, self.bsdfSamples, self.emitterSamples, self.hideEmitters, integrator=abi.INTEGRATOR_DIRECT,
+                              strict_normals=self.strictNormals, **kw)
+        finally:
+            if own:
+                ctx.close()
