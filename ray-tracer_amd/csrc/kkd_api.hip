@@ -46,7 +46,7 @@ struct kkd_ctx {
     HostScene hs;
     DScene ds{};
     /* scene buffers */
-    DevBuf nodes, tris, projTris, positions, normals, texcoords, indices, shapes, materials, emitters, emitterCdf, areaCdf, rtTables,
+    DevBuf nodes, wideNodes, tris, projTris, positions, normals, texcoords, indices, shapes, materials, emitters, emitterCdf, areaCdf, rtTables,
            envTexels, envCdfRows, envCdfCols, envRowWeights;
     /* work buffers */
     DevBuf hits, accum, refN, bsdfRays, bsdfHits, brec0, shadowRays, occluded, lrec, film, counters, apiRays, apiHits;
@@ -112,7 +112,7 @@ void kkd_destroy(kkd_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
-    DevBuf *all[] = { &ctx->nodes, &ctx->tris, &ctx->projTris, &ctx->positions, &ctx->normals, &ctx->texcoords, &ctx->indices, &ctx->shapes, &ctx->materials,
+    DevBuf *all[] = { &ctx->nodes, &ctx->wideNodes, &ctx->tris, &ctx->projTris, &ctx->positions, &ctx->normals, &ctx->texcoords, &ctx->indices, &ctx->shapes, &ctx->materials,
                       &ctx->emitters, &ctx->emitterCdf, &ctx->areaCdf, &ctx->rtTables, &ctx->envTexels, &ctx->envCdfRows, &ctx->envCdfCols,
                       &ctx->envRowWeights, &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->shadowRays,
                       &ctx->occluded, &ctx->lrec, &ctx->film, &ctx->counters, &ctx->apiRays, &ctx->apiHits };
@@ -135,6 +135,7 @@ int kkd_scene_upload(kkd_ctx *ctx, const kkd_scene_desc *sd) {
     int rc;
 #define UP(buf, ptr, n) if ((rc = upload(ctx, ctx->buf, ptr, n)) != KKD_OK) return rc;
     UP(nodes, hs.bvh.nodes.data(), hs.bvh.nodes.size())
+    UP(wideNodes, hs.bvh.wide.data(), hs.bvh.wide.size())
     UP(tris, hs.bvh.tris.data(), hs.bvh.tris.size())
     if (ctx->cfg.flags & KKD_FLAG_PROJECTION_TEST) {
         std::vector<ProjTri> pt; makeProjTris(hs.bvh.tris, pt);
@@ -158,7 +159,7 @@ int kkd_scene_upload(kkd_ctx *ctx, const kkd_scene_desc *sd) {
     KKD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     DScene &d = ctx->ds;
     std::memset(&d, 0, sizeof(d));
-    d.nodes = (const Node4 *)ctx->nodes.p; d.tris = (const LeafTri *)ctx->tris.p;
+    d.nodes = (const Node4 *)ctx->nodes.p; d.tris = (const LeafTri *)ctx->tris.p; d.wideNodes = (const WideNode *)ctx->wideNodes.p;
     d.projTris = (ctx->cfg.flags & KKD_FLAG_PROJECTION_TEST) ? (const ProjTri *)ctx->projTris.p : nullptr;
     d.positions = (const float *)ctx->positions.p; d.normals = (const float *)ctx->normals.p; d.texcoords = (const float *)ctx->texcoords.p;
     d.indices = (const uint32_t *)ctx->indices.p;

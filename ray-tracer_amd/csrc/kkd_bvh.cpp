@@ -181,6 +181,28 @@ struct Collapser {
  * checked through the kernel's own decode, fmaf(q, scale, origin), so the decoded box always encloses the true one. */
 static inline float decodePlane(uint8_t q, float scale, float origin) { return std::fmaf((float)q, scale, origin); }
 
+/* float boxes relative to the node's min corner, rounded outwards (so that origin + rel encloses the true plane) */
+static void widenNode(const Node4F &n, WideNode &out) {
+    std::memset(&out, 0, sizeof(out));
+    const float *mins[3] = { n.minx, n.miny, n.minz }, *maxs[3] = { n.maxx, n.maxy, n.maxz };
+    float *rmins[3] = { out.rminx, out.rminy, out.rminz }, *rmaxs[3] = { out.rmaxx, out.rmaxy, out.rmaxz };
+    float origin[3];
+    for (int a = 0; a < 3; ++a) {
+        float lo = INFINITY;
+        for (int k = 0; k < n.nk; ++k) lo = std::min(lo, mins[a][k]);
+        origin[a] = lo;
+        for (int k = 0; k < 4; ++k) {
+            if (k >= n.nk) { rmins[a][k] = INFINITY; rmaxs[a][k] = INFINITY; continue; }
+            float r0 = mins[a][k] - lo, r1 = maxs[a][k] - lo;
+            while (lo + r0 > mins[a][k]) r0 = std::nextafter(r0, -INFINITY);
+            while (lo + r1 < maxs[a][k]) r1 = std::nextafter(r1, INFINITY);
+            rmins[a][k] = r0; rmaxs[a][k] = r1;
+        }
+    }
+    out.ox = origin[0]; out.oy = origin[1]; out.oz = origin[2];
+    for (int k = 0; k < 4; ++k) out.child[k] = k < n.nk ? n.child[k] : 0u;
+}
+
 static void quantizeNode(const Node4F &n, Node4 &out) {
     std::memset(&out, 0, sizeof(out));
     const float *mins[3] = { n.minx, n.miny, n.minz }, *maxs[3] = { n.maxx, n.maxy, n.maxz };
@@ -214,7 +236,7 @@ static void quantizeNode(const Node4F &n, Node4 &out) {
 }
 
 bool BVH4::build(const float *positions, const uint32_t *indices, uint64_t nTris, const uint32_t *shapeOfPrim, std::string &err) {
-    nodes.clear(); tris.clear(); info = Info();
+    nodes.clear(); this->wide.clear(); tris.clear(); info = Info();
     if (nTris == 0) { err = "scene has no triangles"; return false; }
     if (nTris > (uint64_t)kLeafStartMask) { err = "too many triangles for the 28-bit leaf slot field"; return false; }
     Builder b;
@@ -257,8 +279,8 @@ bool BVH4::build(const float *positions, const uint32_t *indices, uint64_t nTris
     } else {
         c.emit(root, 0, 0);
     }
-    nodes.resize(wide.size());
-    for (size_t i = 0; i < wide.size(); ++i) quantizeNode(wide[i], nodes[i]);
+    nodes.resize(wide.size()); this->wide.resize(wide.size());
+    for (size_t i = 0; i < wide.size(); ++i) { quantizeNode(wide[i], nodes[i]); widenNode(wide[i], this->wide[i]); }
     info.nNodes = nodes.size(); info.nLeafTris = tris.size();
     return true;
 }

@@ -14,6 +14,7 @@ struct BVH4 {
         float bmin[3] = { 0, 0, 0 }, bmax[3] = { 0, 0, 0 };
     };
     std::vector<Node4> nodes;
+    std::vector<WideNode> wide;     /* same tree, float boxes (packet traversal of primary rays) */
     std::vector<LeafTri> tris;
     Info info;
     /* positions: nVerts*3, indices: nTris*3, shapeOfPrim: nTris.  false + err on failure. */

@@ -71,16 +71,19 @@ __device__ __forceinline__ void countTraversal(uint32_t nn, uint32_t nt, DeviceC
     if ((threadIdx.x & 63) == 0) { atomicAdd(&ctr->nodes[cls], (unsigned long long)nn); atomicAdd(&ctr->tris[cls], (unsigned long long)nt); }
 }
 
-template <bool COUNT, bool PROJ, int STACK, int BLOCK>
+template <bool COUNT, bool PROJ, bool PACKET, int STACK, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, 8) kPrimary(DScene sc, BatchParams bp, DHit *__restrict__ hits, DeviceCounters *ctr) {
-    __shared__ uint32_t sstack[STACK * BLOCK];
+    /* PACKET: one wave-uniform stack per wave; else one stack per lane */
+    __shared__ uint32_t sstack[PACKET ? (BLOCK / 64) * kMaxTraversalStack : STACK * BLOCK];
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     const SampleId s = mapWorkItem(bp, i);
     DRay ray; ray.maxt = -1.f; ray.mint = 0.f; ray.ox = ray.oy = ray.oz = 0.f; ray.dx = ray.dy = 0.f; ray.dz = 1.f;
     float sx, sy;
     if (s.active) ray = primaryRay(sc, bp, s, sx, sy);
     uint32_t nn = 0, nt = 0;
-    const DHit h = traverse<false, COUNT, PROJ, STACK, BLOCK>(sc.nodes, PROJ ? (const void *)sc.projTris : (const void *)sc.tris, ray, sstack, nn, nt);
+    const void *triTable = PROJ ? (const void *)sc.projTris : (const void *)sc.tris;
+    const DHit h = PACKET ? traversePacket<COUNT, PROJ>(sc.wideNodes, triTable, ray, sstack + (threadIdx.x >> 6) * kMaxTraversalStack, nn, nt)
+                          : traverse<false, COUNT, PROJ, STACK, BLOCK>(sc.nodes, triTable, ray, sstack, nn, nt);
     if (i < bp.count) hits[i] = h;
     ctr = counterShard(ctr);
     countRays(s.active, &ctr->rays[KKD_RAYS_PRIMARY]);
@@ -409,13 +412,16 @@ static inline uint32_t blocksFor(uint64_t n, uint32_t block) { return (uint32_t)
 
 void launchPrimary(hipStream_t st, bool count, const DScene &sc, const BatchParams &bp, DHit *hits, DeviceCounters *ctr) {
     const dim3 grid(blocksFor(bp.count, 256)), block(256);
+    const bool packet = !(bp.debug & 64u);     /* $KKD_DEBUG bit 64: per-lane walk for primary rays (A/B measurements) */
+#define KKD_LP(C, P, K) hipLaunchKernelGGL((kPrimary<C, P, K, kStackLds, 256>), grid, block, 0, st, sc, bp, hits, ctr)
     if (sc.projTris) {
-        if (count) hipLaunchKernelGGL((kPrimary<true, true, kStackLds, 256>), grid, block, 0, st, sc, bp, hits, ctr);
-        else hipLaunchKernelGGL((kPrimary<false, true, kStackLds, 256>), grid, block, 0, st, sc, bp, hits, ctr);
+        if (count) { if (packet) KKD_LP(true, true, true); else KKD_LP(true, true, false); }
+        else { if (packet) KKD_LP(false, true, true); else KKD_LP(false, true, false); }
     } else {
-        if (count) hipLaunchKernelGGL((kPrimary<true, false, kStackLds, 256>), grid, block, 0, st, sc, bp, hits, ctr);
-        else hipLaunchKernelGGL((kPrimary<false, false, kStackLds, 256>), grid, block, 0, st, sc, bp, hits, ctr);
+        if (count) { if (packet) KKD_LP(true, false, true); else KKD_LP(true, false, false); }
+        else { if (packet) KKD_LP(false, false, true); else KKD_LP(false, false, false); }
     }
+#undef KKD_LP
 }
 
 template <bool ANY, bool COUNT, int OUT>

@@ -216,4 +216,78 @@ __device__ __forceinline__ DHit traverse(const Node4 *__restrict__ nodes, const 
     return hit;
 }
 
+/*
+ * Packet traversal for coherent rays (primary rays: the 64 lanes of a wave hold samples of one pixel or of neighbouring
+ * pixels).  The wave walks the tree ONCE: the current node and the stack are wave-uniform, node (WideNode, float boxes)
+ * and triangle records are fetched through the scalar cache, a child is visited if ANY lane's ray hits its box within
+ * that lane's current [tmin, tmax], children are ordered by the entry distance of their first hitting lane.  Every lane
+ * still tests its own ray against every visited triangle, so the result per ray is that of the per-lane walk (ties
+ * aside).  No divergent control flow, no per-lane stack.
+ * wstack: LDS, kMaxTraversalStack words owned by this wave.  Counters: a lane counts a child it hits (node or the
+ * triangles of a leaf), i.e. what its own walk would have visited.
+ */
+template <bool COUNT, bool PROJ>
+__device__ __forceinline__ DHit traversePacket(const WideNode *__restrict__ wnodes, const void *__restrict__ tris, const DRay &ray,
+                                               uint32_t *wstack, uint32_t &nNodes, uint32_t &nTris) {
+    DHit hit; hit.t = kInf; hit.u = 0.f; hit.v = 0.f; hit.id = kNoHit;
+    const float ox = ray.ox, oy = ray.oy, oz = ray.oz;
+    const float tmin = adaptiveMinT<false>(ray.mint, ox, oy, oz);
+    float tmax = ray.maxt;
+    if (!(tmax > tmin)) tmax = -1.0f;              /* dead lane: no box and no triangle is ever hit */
+    if (__ballot(tmax > tmin) == 0ull) return hit;
+    const float kBig = 0x1p100f, kTiny = 0x1p-100f;
+    const float idx = fabsf(ray.dx) < kTiny ? copysignf(kBig, ray.dx) : 1.0f / ray.dx;
+    const float idy = fabsf(ray.dy) < kTiny ? copysignf(kBig, ray.dy) : 1.0f / ray.dy;
+    const float idz = fabsf(ray.dz) < kTiny ? copysignf(kBig, ray.dz) : 1.0f / ray.dz;
+    WoopRay wr; wr.init(ray.dx, ray.dy, ray.dz);
+    const float4 *tris4 = reinterpret_cast<const float4 *>(tris);
+    if (COUNT) ++nNodes;                           /* the root */
+    int sp = 0;
+    uint32_t cur = 0;
+    /* every wave leaves this loop: each iteration pops or descends in a finite tree; the step bound ends a malformed one */
+    for (int guard = 1 << 24; guard > 0; --guard) {
+        cur = __builtin_amdgcn_readfirstlane(cur);
+        if (!(cur & kLeafBit)) {
+            const WideNode *n = wnodes + cur;
+            const float tbx = (n->ox - ox) * idx, tby = (n->oy - oy) * idy, tbz = (n->oz - oz) * idz;
+            uint32_t dk[4], ck[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ck[k] = n->child[k]; dk[k] = 0xFFFFFFFFu;
+                if (ck[k] == 0u) continue;         /* empty slot (wave-uniform) */
+                const float t0x = fmaf(n->rminx[k], idx, tbx), t1x = fmaf(n->rmaxx[k], idx, tbx);
+                const float t0y = fmaf(n->rminy[k], idy, tby), t1y = fmaf(n->rmaxy[k], idy, tby);
+                const float t0z = fmaf(n->rminz[k], idz, tbz), t1z = fmaf(n->rmaxz[k], idz, tbz);
+                const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
+                const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+                const bool h = tn * 0.999999f <= tf * 1.000001f;
+                const unsigned long long m = __ballot(h);
+                if (COUNT && h) { if (ck[k] & kLeafBit) nTris += ((ck[k] >> 28) & 7u) + 1u; else ++nNodes; }
+                if (m) dk[k] = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tn), __ffsll((long long)m) - 1);   /* tn >= 0: orders as uint */
+            }
+#define KKD_SSWAP(A, B) { if (dk[B] < dk[A]) { const uint32_t td = dk[A]; dk[A] = dk[B]; dk[B] = td; const uint32_t tc = ck[A]; ck[A] = ck[B]; ck[B] = tc; } }
+            KKD_SSWAP(0, 1) KKD_SSWAP(2, 3) KKD_SSWAP(0, 2) KKD_SSWAP(1, 3) KKD_SSWAP(1, 2)
+#undef KKD_SSWAP
+            if (dk[3] != 0xFFFFFFFFu) wstack[sp++] = ck[3];
+            if (dk[2] != 0xFFFFFFFFu) wstack[sp++] = ck[2];
+            if (dk[1] != 0xFFFFFFFFu) wstack[sp++] = ck[1];
+            if (dk[0] != 0xFFFFFFFFu) { cur = ck[0]; continue; }
+        } else {
+            const uint32_t start = cur & kLeafStartMask, cnt = ((cur >> 28) & 7u) + 1u;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const float4 *tp = tris4 + (size_t)(start + i) * 3;
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+                float t, u, v;
+                if (PROJ ? projIntersect(ox, oy, oz, ray.dx, ray.dy, ray.dz, a, b, c, tmin, tmax, t, u, v)
+                         : woopIntersect(wr, ox, oy, oz, a, b, c, tmin, tmax, t, u, v)) {
+                    tmax = t; hit.t = t; hit.u = u; hit.v = v; hit.id = start + i;
+                }
+            }
+        }
+        if (sp == 0) break;
+        cur = wstack[--sp];
+    }
+    return hit;
+}
+
 } /* namespace kkd */

@@ -36,6 +36,16 @@ static constexpr uint32_t kLeafStartMask = 0x0FFFFFFFu;
 static constexpr uint32_t kTraversalDone = 0xFFFFFFFFu;   /* never a leaf reference: LeafTri slots stay below kLeafStartMask */
 static constexpr int kMaxLeafTris = 4;
 
+/* The same tree with full-float child boxes, for the packet traversal of primary rays (one wave = the samples of one pixel
+ * or of a few neighbouring pixels): the node is fetched ONCE per wave through the scalar cache, so its size costs no
+ * per-lane loads.  Planes are stored relative to the node's min corner ("origin"), rounded outwards, so that a slab
+ * distance is one fma per plane: t = rel * (1/d) + (origin - o) * (1/d). */
+struct alignas(128) WideNode {
+    float ox, oy, oz, pad0;
+    float rminx[4], rminy[4], rminz[4], rmaxx[4], rmaxy[4], rmaxz[4];
+    uint32_t child[4];           /* as Node4::child */
+};
+
 /* Triangles in leaf order, 48 bytes: three 16-byte loads.  w components carry ids (bit patterns). */
 struct alignas(16) LeafTri {
     float v0x, v0y, v0z; uint32_t prim;   /* global primitive id = first_prim + primIndex          */
@@ -104,6 +114,7 @@ struct DFilter { float values[32]; float radius, scaleFactor; int32_t border, pa
 
 struct DScene {
     const Node4 *nodes; const LeafTri *tris;
+    const WideNode *wideNodes; /* same indices as nodes */
     const ProjTri *projTris;   /* non-null: leaf test with the reference's projection arithmetic */
     const float *positions; const float *normals; const float *texcoords; const uint32_t *indices;
     const DShape *shapes; const DMaterial *materials; const DEmitter *emitters;
