@@ -35,7 +35,7 @@ def make_workload(name, scale):
         return scenes.sponza_class(w, h), 256, "C2 Sponza-class interior ~260k tris %dx%d 256spp" % (w, h)
     if name == "c3":
         w, h = int(1920 * scale), int(1080 * scale)
-        return scenes.many_lights(w, h), 128, "C3 many-light 10k emitters %dx%d 128spp" % (w, h)
+        return scenes.many_lights(w, h, interior_tris=260_000), 128, "C3 many-light: C2 geometry + 10k emissive triangles %dx%d 128spp" % (w, h)
     if name == "c4":
         w, h = int(3840 * scale), int(2160 * scale)
         return scenes.scanned_mesh(w, h), 512, "C4 10.5M-tri mesh + HDR envmap %dx%d 512spp" % (w, h)
