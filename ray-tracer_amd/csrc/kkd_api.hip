@@ -370,6 +370,9 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     bp.g = g; bp.gShift = gShift; bp.chunks = chunks; bp.spp = rp->spp; bp.sampleFirst = rp->sample_first;
     bp.nB = nB; bp.nL = nL; bp.hideEmitters = rp->hide_emitters != 0;
     bp.integrator = rp->integrator; bp.strictNormals = rp->strict_normals != 0;
+    bp.chunksShift = 32; bp.pixShift = 32;
+    if ((chunks & (chunks - 1)) == 0) { bp.chunksShift = 0; while ((1u << bp.chunksShift) < chunks) ++bp.chunksShift; }
+    if ((bs & (bs - 1)) == 0) { bp.pixShift = 0; while ((1u << bp.pixShift) < bs * bs) ++bp.pixShift; }
     bp.bs = bs; bp.bsPow2 = (bs & (bs - 1)) == 0; bp.nbx = nbx; bp.nby = nby;
     bp.tileIndex = tileIndex; bp.tileCount = tileCount; bp.nTilesMine = nTilesMine; bp.W = W; bp.H = H;
     { const char *dbg = getenv("KKD_DEBUG"); bp.debug = dbg ? (uint32_t)atoi(dbg) : 0u; }
@@ -391,6 +394,10 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     for (uint64_t w0 = 0; w0 < total; w0 += batch) {
         if (ctx->cancel.load()) { cancelled = true; break; }
         bp.w0 = w0; bp.count = (uint32_t)std::min<uint64_t>(batch, total - w0);
+        {   /* w0 is a multiple of 256 and g divides 256: lane group = w0 / g + (i >> gShift) */
+            const uint64_t group0 = w0 >> gShift, slot0 = group0 / chunks, pixPerTile = (uint64_t)bs * bs;
+            bp.chunk0 = (uint32_t)(group0 % chunks); bp.pin0 = (uint32_t)(slot0 % pixPerTile); bp.tile0 = (uint32_t)(slot0 / pixPerTile);
+        }
         if (timeStages) hipEventRecord(ctx->events[ev++], st);
         launchPrimary(st, count, ctx->ds, bp, wb.hits, ctr); launches[KKD_STAGE_PRIMARY]++;
         if (timeStages) hipEventRecord(ctx->events[ev++], st);

@@ -19,6 +19,9 @@ struct BatchParams {
     uint64_t w0; uint64_t seed;
     uint32_t count, stride;          /* stride: element pitch between the per-sample planes of multi-sample buffers */
     uint32_t g, gShift, chunks, spp, sampleFirst;
+    /* position of the batch's first lane group, split on the host so that the device needs 32-bit arithmetic only:
+     * group(w0) = (tile0 * bs^2 + pin0) * chunks + chunk0 */
+    uint32_t chunk0, pin0, tile0, chunksShift /* log2(chunks) or 32 */, pixShift /* log2(bs^2) or 32 */;
     uint32_t nB, nL, hideEmitters;
     uint32_t integrator, strictNormals;   /* KKD_INTEGRATOR_*; 'strictNormals' of the stock direct plugin */
     uint32_t bs, bsPow2, nbx, nby, tileIndex, tileCount, nTilesMine;

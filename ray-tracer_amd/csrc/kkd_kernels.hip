@@ -33,15 +33,20 @@ __device__ __forceinline__ uint32_t compact1by1(uint32_t x) {
 
 __device__ __forceinline__ SampleId mapWorkItem(const BatchParams &bp, uint32_t i) {
     SampleId s;
-    const uint64_t w = bp.w0 + i;
-    const uint64_t group = w >> bp.gShift;
-    const uint32_t j = (uint32_t)w & (bp.g - 1u);
-    const uint32_t chunk = (uint32_t)(group % bp.chunks);
-    const uint64_t slot = group / bp.chunks;
-    const uint32_t pixPerTile = bp.bs * bp.bs;
-    const uint32_t tileLocal = (uint32_t)(slot / pixPerTile), pin = (uint32_t)(slot % pixPerTile);
+    /* 32-bit arithmetic only (64-bit division costs hundreds of instructions per lane, and this runs in three kernels):
+     * the host has split the batch origin into (tile0, pin0, chunk0); shifts when the divisors are powers of two */
+    const uint32_t j = i & (bp.g - 1u);
+    const uint32_t c = bp.chunk0 + (i >> bp.gShift);
+    uint32_t chunk, sAdd;
+    if (bp.chunksShift < 32u) { sAdd = c >> bp.chunksShift; chunk = c & (bp.chunks - 1u); }
+    else { sAdd = c / bp.chunks; chunk = c - sAdd * bp.chunks; }
+    const uint32_t p = bp.pin0 + sAdd, pixPerTile = bp.bs * bp.bs;
+    uint32_t tAdd, pin;
+    if (bp.pixShift < 32u) { tAdd = p >> bp.pixShift; pin = p & (pixPerTile - 1u); }
+    else { tAdd = p / pixPerTile; pin = p - tAdd * pixPerTile; }
+    const uint32_t tileLocal = bp.tile0 + tAdd;
     const uint32_t tile = bp.tileIndex + tileLocal * bp.tileCount;
-    const uint32_t tx = tile % bp.nbx, ty = tile / bp.nbx;
+    const uint32_t ty = tile / bp.nbx, tx = tile - ty * bp.nbx;
     uint32_t px, py;
     if (bp.bsPow2) { px = compact1by1(pin); py = compact1by1(pin >> 1); }
     else { px = pin % bp.bs; py = pin / bp.bs; }
