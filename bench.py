@@ -79,12 +79,20 @@ def main():
     from kkdirect import abi
     if not torch.cuda.is_available() or kkdirect.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: libkkdirect has no CPU fallback")
+    # $KKD_BENCH_BACKEND=gloo rehearses the N-rank path on a box with fewer GPUs than ranks (ranks share devices, the film
+    # merge is an all_reduce because gloo has no CUDA reduce); the measured configuration is always nccl = RCCL
+    backend = os.environ.get("KKD_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     scene, spp, label = make_workload(args.workload, args.scale)
     if args.spp:
@@ -105,7 +113,10 @@ def main():
     def step():
         st = ctx.render_device(film.data_ptr(), bsdf_samples=n_b, light_samples=n_l, **kw)
         if dist is not None:
-            dist.reduce(film, dst=0)      # film merge = Film::put(block): sum of per-rank films
+            if backend == "nccl":
+                dist.reduce(film, dst=0)      # film merge = Film::put(block): sum of per-rank films
+            else:
+                dist.all_reduce(film)
         return st
 
     def fence():
@@ -172,7 +183,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "mrays_per_s": round(rays / elapsed / 1e6, 3),
             "config": {"workload": label, "spp_total": kw["spp"] if args.split == "tile" else spp * world, "bsdfSamples": n_b, "lightSamples": n_l,
-                       "split": args.split, "leaf_test": args.leaf_test, "triangles": int(scene._nt), "scene_upload_s": round(upload_s, 2)},
+                       "split": args.split, "backend": backend, "leaf_test": args.leaf_test, "triangles": int(scene._nt), "scene_upload_s": round(upload_s, 2)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
     ctx.close()
