@@ -49,6 +49,7 @@ struct kkd_ctx {
     DevBuf nodes, wideNodes, tris, projTris, positions, normals, texcoords, indices, shapes, materials, emitters, emitterCdf, areaCdf, rtTables,
            envTexels, envCdfRows, envCdfCols, envRowWeights;
     /* work buffers */
+    DevBuf contRecs, contStacks, contCount;
     DevBuf hits, accum, refN, bsdfRays, bsdfHits, brec0, shadowRays, occluded, lrec, film, counters, apiRays, apiHits;
     std::vector<hipEvent_t> events;
 };
@@ -114,7 +115,7 @@ void kkd_destroy(kkd_ctx *ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     DevBuf *all[] = { &ctx->nodes, &ctx->wideNodes, &ctx->tris, &ctx->projTris, &ctx->positions, &ctx->normals, &ctx->texcoords, &ctx->indices, &ctx->shapes, &ctx->materials,
                       &ctx->emitters, &ctx->emitterCdf, &ctx->areaCdf, &ctx->rtTables, &ctx->envTexels, &ctx->envCdfRows, &ctx->envCdfCols,
-                      &ctx->envRowWeights, &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->shadowRays,
+                      &ctx->envRowWeights, &ctx->contRecs, &ctx->contStacks, &ctx->contCount, &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->shadowRays,
                       &ctx->occluded, &ctx->lrec, &ctx->film, &ctx->counters, &ctx->apiRays, &ctx->apiHits };
     for (DevBuf *b : all) b->release();
     for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
@@ -352,12 +353,22 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     auto need = [&](DevBuf &b, size_t bytes) { if (e == hipSuccess) e = b.ensure(bytes); };
     need(ctx->hits, S * sizeof(DHit)); need(ctx->accum, S * 16); need(ctx->refN, S * 16);
     need(ctx->bsdfRays, S * nB * sizeof(DRay)); need(ctx->bsdfHits, S * nB * sizeof(DHit)); need(ctx->brec0, S * nB * 16);
+    /* continuation buffer of the two-launch traversal: a quarter of the largest ray launch may be parked */
+    static const int capClosest = [] { const char *e = getenv("KKD_ITER_CAP_CLOSEST"); return e ? atoi(e) : 28; }();
+    static const int capAny = [] { const char *e = getenv("KKD_ITER_CAP_ANY"); return e ? atoi(e) : 20; }();
+    const uint64_t contCap = std::min<uint64_t>(((uint64_t)S * std::max(nB, nL) / 2 / kContShards + 128) * kContShards, 0x7fffffffull);   /* two halves of n/4 records */
+    need(ctx->contRecs, contCap * sizeof(ContRec)); need(ctx->contStacks, contCap * 16 * sizeof(uint32_t)); need(ctx->contCount, 2 * kContShards * 32 * sizeof(uint32_t));
     need(ctx->shadowRays, S * nL * sizeof(DRay)); need(ctx->occluded, S * nL * 4); need(ctx->lrec, S * nL * 16);
     need(ctx->counters, kCounterShards * sizeof(DeviceCounters));
     if (!devFilm) need(ctx->film, (size_t)W * H * 5 * sizeof(float));
     if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? KKD_ERR_NOMEM : KKD_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
     float *film = devFilm ? devFilm : (float *)ctx->film.p;
 
+    TraceContinuation cont; cont.recs = (ContRec *)ctx->contRecs.p; cont.stacks = (uint4 *)ctx->contStacks.p; cont.count = (uint32_t *)ctx->contCount.p;
+    cont.perShard = (uint32_t)(contCap / kContShards); cont.iterCap = 0;
+    static const int capLater = [] { const char *e = getenv("KKD_ITER_CAP_LATER"); return e ? atoi(e) : 8; }();
+    static const int rounds = [] { const char *e = getenv("KKD_TRACE_ROUNDS"); return e ? atoi(e) : 2; }();
+    cont.iterCapLater = capLater; cont.rounds = rounds;
     WaveBuffers wb;
     wb.hits = (DHit *)ctx->hits.p; wb.accum = (float4 *)ctx->accum.p; wb.refN = (float4 *)ctx->refN.p;
     wb.bsdfRays = (DRay *)ctx->bsdfRays.p; wb.bsdfHits = (DHit *)ctx->bsdfHits.p; wb.brec0 = (float4 *)ctx->brec0.p;
@@ -404,11 +415,16 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         launchShade(st, ctx->ds, bp, wb); launches[KKD_STAGE_SHADE]++;
         if (timeStages) hipEventRecord(ctx->events[ev++], st);
         /* all nB planes are contiguous when count == stride; otherwise trace plane by plane */
-        if (bp.count == bp.stride) { launchTrace(st, ctx->ds, wb.bsdfRays, (uint64_t)S * nB, false, count, 0, wb.bsdfHits, ctr, KKD_RAYS_BSDF); launches[KKD_STAGE_BSDF]++; }
-        else for (uint32_t b = 0; b < nB; ++b) { launchTrace(st, ctx->ds, wb.bsdfRays + (size_t)b * S, bp.count, false, count, 0, wb.bsdfHits + (size_t)b * S, ctr, KKD_RAYS_BSDF); launches[KKD_STAGE_BSDF]++; }
+        auto trace = [&](const DRay *rays, uint64_t n, bool any, void *out, int cls) {
+            TraceContinuation c = cont; c.iterCap = any ? capAny : capClosest;
+            if (c.iterCap > 0) launchTracePhased(st, ctx->ds, rays, n, any, count, out, ctr, cls, c);
+            else launchTrace(st, ctx->ds, rays, n, any, count, any ? 2 : 0, out, ctr, cls);
+        };
+        if (bp.count == bp.stride) { trace(wb.bsdfRays, (uint64_t)S * nB, false, wb.bsdfHits, KKD_RAYS_BSDF); launches[KKD_STAGE_BSDF]++; }
+        else for (uint32_t b = 0; b < nB; ++b) { trace(wb.bsdfRays + (size_t)b * S, bp.count, false, wb.bsdfHits + (size_t)b * S, KKD_RAYS_BSDF); launches[KKD_STAGE_BSDF]++; }
         if (timeStages) hipEventRecord(ctx->events[ev++], st);
-        if (bp.count == bp.stride) { launchTrace(st, ctx->ds, wb.shadowRays, (uint64_t)S * nL, true, count, 2, wb.occluded, ctr, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++; }
-        else for (uint32_t l = 0; l < nL; ++l) { launchTrace(st, ctx->ds, wb.shadowRays + (size_t)l * S, bp.count, true, count, 2, wb.occluded + (size_t)l * S, ctr, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++; }
+        if (bp.count == bp.stride) { trace(wb.shadowRays, (uint64_t)S * nL, true, wb.occluded, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++; }
+        else for (uint32_t l = 0; l < nL; ++l) { trace(wb.shadowRays + (size_t)l * S, bp.count, true, (uint32_t *)wb.occluded + (size_t)l * S, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++; }
         if (timeStages) hipEventRecord(ctx->events[ev++], st);
         launchResolve(st, ctx->ds, bp, wb, film, ctr); launches[KKD_STAGE_RESOLVE]++;
         if (timeStages) hipEventRecord(ctx->events[ev++], st);

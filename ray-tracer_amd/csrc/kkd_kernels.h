@@ -46,6 +46,18 @@ void launchPrimary(hipStream_t st, bool count, const DScene &sc, const BatchPara
 /* outMode: 0 = DHit with LeafTri slot, 1 = DHit with global primitive id, 2 = uint32 occlusion flags (anyHit only) */
 /* rayClass: which DeviceCounters slot the launch accounts to */
 void launchTrace(hipStream_t st, const DScene &sc, const DRay *rays, uint64_t n, bool anyHit, bool count, int outMode, void *out, DeviceCounters *ctr, int rayClass);
+/* A ray parked by kTraceFirst after its iteration budget: everything Walk needs to go on (32 bytes + 16 stack words). */
+struct alignas(16) ContRec { uint32_t ray, cur, sp; float tmax, t, u, v; uint32_t id; };
+/* stacks: 16 words (= kStackLds, kkd_trace.h) per record */
+/* The buffer is cut into kContShards regions of perShard records, each with its own fill counter on its own 128-byte
+ * line (count[shard * 32]): one counter for all waves would serialise at ~88 M atomics/s, like the ray counters did. */
+static constexpr uint32_t kContShards = 1024;
+struct TraceContinuation { ContRec *recs; uint4 *stacks; uint32_t *count; uint32_t perShard; int iterCap /* first round */, iterCapLater, rounds; };
+/* Two-launch variant of launchTrace for the render path (outMode 0 or 2): waves stop after cont.iterCap steps, the few lanes
+ * still walking are parked in cont and finished by a second, densely packed launch.  cont.count must be zero on entry
+ * (the launcher clears the counters). */
+void launchTracePhased(hipStream_t st, const DScene &sc, const DRay *rays, uint64_t n, bool anyHit, bool count, void *out, DeviceCounters *ctr,
+                       int rayClass, const TraceContinuation &cont);
 void launchShade(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb);
 void launchDevelop(hipStream_t st, const float *film, uint64_t nPixels, int pixelFormat, float *out);
 void launchResolve(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb, float *film, DeviceCounters *ctr);

@@ -16,6 +16,7 @@
  * g samples of ONE pixel, so primary rays of a wave are maximally coherent and the film splat can be
  * reduced across the group before any atomic is issued.
  */
+#include <algorithm>
 #include "kkd_kernels.h"
 #include "kkd_trace.h"
 #include "kkd_bsdf.h"
@@ -95,6 +96,8 @@ __global__ void __launch_bounds__(BLOCK, 8) kPrimary(DScene sc, BatchParams bp, 
     if (COUNT) countTraversal(nn, nt, ctr, KKD_RAYS_PRIMARY);
 }
 
+template <int OUT> __device__ __forceinline__ void storeTraceResult(void *__restrict__ out, uint64_t i, DHit h, const LeafTri *__restrict__ tris);
+
 /* ---- generic ray-buffer traversal ------------------------------------------------------------------ */
 /* OUT: 0 = DHit with LeafTri slot (internal), 1 = DHit with global primitive id (C ABI), 2 = occlusion word */
 template <bool ANY, bool COUNT, int OUT, bool PROJ, int STACK, int BLOCK>
@@ -106,18 +109,109 @@ __global__ void __launch_bounds__(BLOCK, 8) kTrace(const Node4 *__restrict__ nod
     if (i < n) ray = rays[i];
     uint32_t nn = 0, nt = 0;
     DHit h = traverse<ANY, COUNT, PROJ, STACK, BLOCK>(nodes, PROJ ? (const void *)projTris : (const void *)tris, ray, sstack, nn, nt);
-    if (i < n) {
-        if (OUT == 2) reinterpret_cast<uint32_t *>(out)[i] = h.id != kNoHit ? 1u : 0u;
-        else {
-            if (OUT == 1 && h.id != kNoHit) h.id = tris[h.id].prim;
-            if (OUT == 0 && h.id != kNoHit && tris[h.id].emitter == 0u) h.id |= kHitNotEmitter;
-            reinterpret_cast<DHit *>(out)[i] = h;
-        }
-    }
+    if (i < n) storeTraceResult<OUT>(out, i, h, tris);
     if (ctr) {
         ctr = counterShard(ctr);
         const bool traced = i < n && ray.maxt > adaptiveMinT<ANY>(ray.mint, ray.ox, ray.oy, ray.oz);
         countRays(traced, &ctr->rays[cls]);
+        if (COUNT) countTraversal(nn, nt, ctr, cls);
+    }
+}
+
+/* ---- the same walk in two launches --------------------------------------------------------------------------------
+ * A wave of incoherent rays runs as long as its longest lane: on C2 ~37 steps for a mean path of ~22, so in the late
+ * steps most lanes idle while every instruction is still issued for the whole wave.  the first round therefore stops every
+ * wave after iterCap steps; a lane that is not done parks its state (current reference, stack, clipped interval, best
+ * hit) in a continuation record, and the next round, launched over the parked rays only, packs them 64 to a wave and
+ * walks on (kTraceRound).  Lanes whose stack has spilled into private memory, or that find the continuation buffer full, simply
+ * walk on in the first launch. */
+template <int OUT>
+__device__ __forceinline__ void storeTraceResult(void *__restrict__ out, uint64_t i, DHit h, const LeafTri *__restrict__ tris) {
+    if (OUT == 2) reinterpret_cast<uint32_t *>(out)[i] = h.id != kNoHit ? 1u : 0u;
+    else {
+        if (OUT == 1 && h.id != kNoHit) h.id = tris[h.id].prim;
+        if (OUT == 0 && h.id != kNoHit && tris[h.id].emitter == 0u) h.id |= kHitNotEmitter;
+        reinterpret_cast<DHit *>(out)[i] = h;
+    }
+}
+
+static_assert(kStackLds == 16, "TraceContinuation stores 16 stack words per parked ray");
+
+/* One round.  FIRST: lanes take rays [0, n) of the ray buffer; else lanes take the records parked in `in` by the round
+ * before.  next.iterCap > 0: stop after that many steps and park what is still walking in `next`; else walk to the end. */
+template <bool ANY, bool COUNT, int OUT, bool PROJ, bool FIRST, int STACK, int BLOCK>
+__global__ void __launch_bounds__(BLOCK, 8) kTraceRound(const Node4 *__restrict__ nodes, const LeafTri *__restrict__ tris, const ProjTri *__restrict__ projTris,
+                                                        const DRay *__restrict__ rays, uint64_t n, void *__restrict__ out, DeviceCounters *ctr, int cls,
+                                                        TraceContinuation in, TraceContinuation next) {
+    __shared__ uint32_t sstack[STACK * BLOCK];
+    DRay ray; ray.maxt = -1.f; ray.mint = 0.f; ray.ox = ray.oy = ray.oz = 0.f; ray.dx = ray.dy = 0.f; ray.dz = 1.f;
+    ContRec r; r.ray = 0; r.cur = kTraversalDone; r.sp = 0; r.tmax = -1.f; r.t = kInf; r.u = r.v = 0.f; r.id = kNoHit;
+    bool mine;                      /* this lane holds a ray */
+    size_t inSlot = 0;
+    if (FIRST) {
+        const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+        mine = i < n;
+        if (mine) { ray = rays[i]; r.ray = (uint32_t)i; }
+    } else {
+        /* block -> (shard, chunk of BLOCK records of that shard); the grid is sized for full shards */
+        const uint32_t shard = blockIdx.x % kContShards, chunk = blockIdx.x / kContShards;
+        const uint32_t nParked = min(in.count[shard * 32u], in.perShard);
+        if (chunk * BLOCK >= nParked) return;                   /* block-uniform */
+        const uint32_t e = chunk * BLOCK + threadIdx.x;
+        mine = e < nParked;
+        inSlot = (size_t)shard * in.perShard + e;
+        if (mine) { r = in.recs[inSlot]; ray = rays[r.ray]; }
+    }
+    uint32_t nn = 0, nt = 0;
+    const void *triTable = PROJ ? (const void *)projTris : (const void *)tris;
+    Walk<ANY, COUNT, PROJ, STACK, BLOCK> w;
+    uint32_t ovf[kStackOverflow];
+    w.begin(ray);
+    const bool traced = FIRST && mine && !w.finished();
+    if (!FIRST) {
+        w.cur = r.cur; w.sp = (int)r.sp; w.tmax = r.tmax; w.hit.t = r.t; w.hit.u = r.u; w.hit.v = r.v; w.hit.id = r.id;
+        if (mine) {
+#pragma unroll
+            for (int q = 0; q < STACK / 4; ++q) {
+                const uint4 s4 = in.stacks[inSlot * (STACK / 4) + q];
+                sstack[(4 * q) * BLOCK + threadIdx.x] = s4.x; sstack[(4 * q + 1) * BLOCK + threadIdx.x] = s4.y;
+                sstack[(4 * q + 2) * BLOCK + threadIdx.x] = s4.z; sstack[(4 * q + 3) * BLOCK + threadIdx.x] = s4.w;
+            }
+        }
+    }
+    bool parked = false;
+    if (next.iterCap > 0) {
+        w.run(nodes, triTable, sstack, ovf, nn, nt, next.iterCap);
+        const bool unfinished = !w.finished();
+        if (__ballot(unfinished) != 0ull) {
+            const bool want = unfinished && w.sp <= STACK;      /* a stack that has spilled into private memory stays here */
+            const unsigned long long m = __ballot(want);
+            const uint32_t shard = blockIdx.x % kContShards;
+            uint32_t base = 0;
+            if (m != 0ull) {
+                const int leader = __ffsll((long long)m) - 1;
+                if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(next.count + shard * 32u, (uint32_t)__popcll(m));
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+            }
+            const uint32_t rank = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            parked = want && rank < next.perShard;              /* a full shard: walk on instead */
+            const size_t slot = (size_t)shard * next.perShard + rank;
+            if (parked) {
+                ContRec o; o.ray = r.ray; o.cur = w.cur; o.sp = (uint32_t)w.sp; o.tmax = w.tmax; o.t = w.hit.t; o.u = w.hit.u; o.v = w.hit.v; o.id = w.hit.id;
+                next.recs[slot] = o;
+#pragma unroll
+                for (int q = 0; q < STACK / 4; ++q)
+                    next.stacks[slot * (STACK / 4) + q] = make_uint4(sstack[(4 * q) * BLOCK + threadIdx.x], sstack[(4 * q + 1) * BLOCK + threadIdx.x],
+                                                                     sstack[(4 * q + 2) * BLOCK + threadIdx.x], sstack[(4 * q + 3) * BLOCK + threadIdx.x]);
+                w.cur = kTraversalDone;
+            }
+        }
+    }
+    if (__ballot(!w.finished()) != 0ull) w.run(nodes, triTable, sstack, ovf, nn, nt, 1 << 24);
+    if (mine && !parked) storeTraceResult<OUT>(out, r.ray, w.hit, tris);
+    if (ctr) {
+        ctr = counterShard(ctr);
+        if (FIRST) countRays(traced, &ctr->rays[cls]);
         if (COUNT) countTraversal(nn, nt, ctr, cls);
     }
 }
@@ -444,6 +538,46 @@ void launchTrace(hipStream_t st, const DScene &sc, const DRay *rays, uint64_t n,
         if (outMode == 0) { if (count) launchTraceT<false, true, 0>(st, sc, rays, n, out, ctr, cls); else launchTraceT<false, false, 0>(st, sc, rays, n, out, ctr, cls); }
         else { if (count) launchTraceT<false, true, 1>(st, sc, rays, n, out, ctr, cls); else launchTraceT<false, false, 1>(st, sc, rays, n, out, ctr, cls); }
     }
+}
+
+template <bool ANY, bool COUNT, int OUT, bool PROJ>
+static void launchPhasedT(hipStream_t st, const DScene &sc, const DRay *rays, uint64_t n, void *out, DeviceCounters *ctr, int cls, const TraceContinuation &cont) {
+    /* rounds: [0, cap) on all rays, then cap more steps on what is left, ..., the last round walks to the end.  The two
+     * halves of the continuation buffer alternate as input and output. */
+    TraceContinuation bufs[2] = { cont, cont };
+    const uint32_t half = cont.perShard / 2;
+    bufs[0].perShard = bufs[1].perShard = half;
+    bufs[1].recs = cont.recs + (size_t)kContShards * half; bufs[1].stacks = cont.stacks + (size_t)kContShards * half * (kStackLds / 4);
+    bufs[1].count = cont.count + kContShards * 32;
+    hipMemsetAsync(cont.count, 0, 2 * kContShards * 32 * sizeof(uint32_t), st);
+    const int rounds = cont.rounds < 2 ? 2 : cont.rounds;
+    /* a shard cannot hold more than its share of the rays of this launch */
+    const uint64_t perShardMax = std::min<uint64_t>(half, (n + kContShards - 1) / kContShards + 256);
+    const dim3 resumeGrid(kContShards * blocksFor(perShardMax, 256)), block(256);
+    for (int r = 0; r < rounds; ++r) {
+        TraceContinuation in = bufs[(r + 1) & 1], next = bufs[r & 1];
+        next.iterCap = (r + 1 < rounds) ? (r == 0 ? cont.iterCap : cont.iterCapLater) : 0;
+        if (r >= 2 && next.iterCap > 0) hipMemsetAsync(next.count, 0, kContShards * 32 * sizeof(uint32_t), st);
+        if (r == 0) hipLaunchKernelGGL((kTraceRound<ANY, COUNT, OUT, PROJ, true, kStackLds, 256>), dim3(blocksFor(n, 256)), block, 0, st,
+                                       sc.nodes, sc.tris, sc.projTris, rays, n, out, ctr, cls, in, next);
+        else hipLaunchKernelGGL((kTraceRound<ANY, COUNT, OUT, PROJ, false, kStackLds, 256>), resumeGrid, block, 0, st,
+                                sc.nodes, sc.tris, sc.projTris, rays, n, out, ctr, cls, in, next);
+    }
+}
+
+void launchTracePhased(hipStream_t st, const DScene &sc, const DRay *rays, uint64_t n, bool anyHit, bool count, void *out, DeviceCounters *ctr,
+                       int cls, const TraceContinuation &cont) {
+    if (n == 0) return;
+    const bool proj = sc.projTris != nullptr;
+#define KKD_PH(A, C, O, P) launchPhasedT<A, C, O, P>(st, sc, rays, n, out, ctr, cls, cont)
+    if (anyHit) {
+        if (count) { if (proj) KKD_PH(true, true, 2, true); else KKD_PH(true, true, 2, false); }
+        else { if (proj) KKD_PH(true, false, 2, true); else KKD_PH(true, false, 2, false); }
+    } else {
+        if (count) { if (proj) KKD_PH(false, true, 0, true); else KKD_PH(false, true, 0, false); }
+        else { if (proj) KKD_PH(false, false, 0, true); else KKD_PH(false, false, 0, false); }
+    }
+#undef KKD_PH
 }
 
 void launchShade(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb) {

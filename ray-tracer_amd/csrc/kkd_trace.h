@@ -107,6 +107,119 @@ template <bool ANY> __device__ __forceinline__ float adaptiveMinT(float mint, fl
     return mint;
 }
 
+/* The per-lane walk as a resumable object: begin() derives the per-ray constants, run() advances every lane of the wave by
+ * at most iterCap steps (all state -- current reference, stack pointer, clipped interval, best hit -- stays in the
+ * object and in the lane's stack), so a kernel can stop a wave whose last few lanes are still walking, park those lanes
+ * in memory and let a later, densely packed launch finish them (kTraceFirst / kTraceResume). */
+template <bool ANY, bool COUNT, bool PROJ, int STACK, int BLOCK>
+struct Walk {
+    /* (the private part of the stack, kStackOverflow words, is the caller's array: an array member would pin the whole
+     * object in scratch memory) */
+    DHit hit; float ox, oy, oz, dx, dy, dz, tmin, tmax, idx, idy, idz; WoopRay wr; uint32_t cur; int sp;
+
+    __device__ __forceinline__ void begin(const DRay &ray) {
+        hit.t = kInf; hit.u = 0.f; hit.v = 0.f; hit.id = kNoHit;
+        ox = ray.ox; oy = ray.oy; oz = ray.oz; dx = ray.dx; dy = ray.dy; dz = ray.dz;
+        tmin = adaptiveMinT<ANY>(ray.mint, ox, oy, oz);
+        tmax = ray.maxt;
+        /* A zero direction component would give 1/d = inf and 0 * inf = NaN for an origin lying exactly on a slab plane
+         * (rays aimed along an axis at mesh vertices do that); a huge finite reciprocal keeps such a slab "inside". */
+        const float kBig = 0x1p100f, kTiny = 0x1p-100f;
+        idx = fabsf(dx) < kTiny ? copysignf(kBig, dx) : 1.0f / dx;
+        idy = fabsf(dy) < kTiny ? copysignf(kBig, dy) : 1.0f / dy;
+        idz = fabsf(dz) < kTiny ? copysignf(kBig, dz) : 1.0f / dz;
+        wr.init(dx, dy, dz);
+        sp = 0;
+        cur = (tmax > tmin) ? 0u : kTraversalDone;      /* cur: inner node index | leaf reference (kLeafBit) | kTraversalDone */
+    }
+    __device__ __forceinline__ bool finished() const { return cur == kTraversalDone; }
+
+    __device__ __forceinline__ void run(const Node4 *__restrict__ nodes, const void *__restrict__ tris, uint32_t *sstack, uint32_t *ovf,
+                                        uint32_t &nNodes, uint32_t &nTris, int iterCap) {
+        const bool negx = idx < 0.f, negy = idy < 0.f, negz = idz < 0.f;
+        const uint4 *nodes4 = reinterpret_cast<const uint4 *>(nodes);
+        const float4 *tris4 = reinterpret_cast<const float4 *>(tris);
+        const int tid = threadIdx.x;
+        DRay ray; ray.dx = dx; ray.dy = dy; ray.dz = dz;   /* projIntersect reads the direction */
+#define KKD_PUSH(V) { if (sp < STACK) sstack[sp * BLOCK + tid] = (V); else ovf[sp - STACK] = (V); ++sp; }
+/* the LDS read is unconditional and the private read a separate, rarely taken branch: one select between the two
+ * pointers would turn every pop into a flat load, which goes the long way round through the texture addresser */
+#define KKD_POP() { if (sp == 0) cur = kTraversalDone; else { --sp; cur = sstack[(sp < STACK ? sp : STACK - 1) * BLOCK + tid]; \
+                    if (sp >= STACK) cur = ovf[sp - STACK]; } }
+        /* One step per iteration and lane: a node visit or ONE triangle test, so a lane at a leaf and a lane at a node both
+         * make progress and the iteration costs one node visit plus one triangle test, not the longest leaf of the wave.
+         * Every wave leaves this loop: the walk is finite on a tree, and the step bound ends it on a malformed one. */
+        for (int guard = iterCap; guard > 0; --guard) {
+            const bool atNode = !(cur & kLeafBit);
+            const bool atLeaf = !atNode && cur != kTraversalDone;
+            const unsigned long long leafLanes = __ballot(atLeaf);
+            const bool anyNode = __ballot(atNode) != 0ull;
+            if (!anyNode && leafLanes == 0ull) break;
+            if (atNode) {
+                if (COUNT) ++nNodes;
+                const uint4 *n = nodes4 + (size_t)cur * 4;
+                const uint4 hd = n[0], ch = n[1], qa = n[2], qb = n[3];
+                const float gx = __uint_as_float(hd.x), gy = __uint_as_float(hd.y), gz = __uint_as_float(hd.z);
+                const float sx = __uint_as_float((hd.w & 0xffu) << 23), sy = __uint_as_float(((hd.w >> 8) & 0xffu) << 23),
+                            sz = __uint_as_float(((hd.w >> 16) & 0xffu) << 23);
+                float d0, d1, d2, d3;
+                /* Slab test in the node's grid: t(plane q) = (origin + q * scale - o) / d = q * ta + tb, so a plane costs one
+                 * byte->float conversion and one fma.  The near / far plane of each axis is picked by the sign of the ray
+                 * direction for all four children at once (one select of the packed byte quadruple).  The 1e-6 slack on
+                 * both sides covers the rounding of ta, tb (the builder's enclosure check covers the grid itself). */
+                const float tax = sx * idx, tay = sy * idy, taz = sz * idz;
+                const float tbx = (gx - ox) * idx, tby = (gy - oy) * idy, tbz = (gz - oz) * idz;
+                const uint32_t nx4 = negx ? qa.w : qa.x, fx4 = negx ? qa.x : qa.w;
+                const uint32_t ny4 = negy ? qb.x : qa.y, fy4 = negy ? qa.y : qb.x;
+                const uint32_t nz4 = negz ? qb.y : qa.z, fz4 = negz ? qa.z : qb.y;
+    #define KKD_SLAB(D, K, C) { \
+                const float tnx = fmaf((float)((nx4 >> (8 * K)) & 0xffu), tax, tbx), tfx = fmaf((float)((fx4 >> (8 * K)) & 0xffu), tax, tbx); \
+                const float tny = fmaf((float)((ny4 >> (8 * K)) & 0xffu), tay, tby), tfy = fmaf((float)((fy4 >> (8 * K)) & 0xffu), tay, tby); \
+                const float tnz = fmaf((float)((nz4 >> (8 * K)) & 0xffu), taz, tbz), tfz = fmaf((float)((fz4 >> (8 * K)) & 0xffu), taz, tbz); \
+                const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin)); \
+                const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tmax)); \
+                D = (tn * 0.999999f <= tf * 1.000001f && (C) != 0u) ? tn : kInf; }
+                KKD_SLAB(d0, 0, ch.x)
+                KKD_SLAB(d1, 1, ch.y)
+                KKD_SLAB(d2, 2, ch.z)
+                KKD_SLAB(d3, 3, ch.w)
+    #undef KKD_SLAB
+                uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+    #define KKD_CSWAP(DA, CA, DB, CB) { const bool s = DB < DA; const float td = s ? DB : DA; DB = s ? DA : DB; DA = td; \
+                                        const uint32_t tc = s ? CB : CA; CB = s ? CA : CB; CA = tc; }
+                KKD_CSWAP(d0, c0, d1, c1) KKD_CSWAP(d2, c2, d3, c3) KKD_CSWAP(d0, c0, d2, c2) KKD_CSWAP(d1, c1, d3, c3) KKD_CSWAP(d1, c1, d2, c2)
+    #undef KKD_CSWAP
+                if (d0 < kInf) {
+                    if (d3 < kInf) KKD_PUSH(c3)
+                    if (d2 < kInf) KKD_PUSH(c2)
+                    if (d1 < kInf) KKD_PUSH(c1)
+                    cur = c0;
+                } else KKD_POP()
+            }
+            {
+                if (atLeaf) {
+                    const uint32_t slot = cur & kLeafStartMask;
+                    if (COUNT) ++nTris;
+                    const float4 *tp = tris4 + (size_t)slot * 3;
+                    const float4 a = tp[0], b = tp[1], c = tp[2];
+                    float t, u, v;
+                    bool done = false;
+                    if (PROJ ? projIntersect(ox, oy, oz, ray.dx, ray.dy, ray.dz, a, b, c, tmin, tmax, t, u, v)
+                             : woopIntersect(wr, ox, oy, oz, a, b, c, tmin, tmax, t, u, v)) {
+                        tmax = t; hit.t = t; hit.u = u; hit.v = v; hit.id = slot;
+                        done = ANY;
+                    }
+                    if (done) cur = kTraversalDone;
+                    else if (cur & (7u << 28)) cur = cur - (1u << 28) + 1u;   /* next triangle of this leaf */
+                    else KKD_POP()
+                }
+            }
+        }
+#undef KKD_PUSH
+#undef KKD_POP
+    }
+};
+
 /*
  * ANY      : stop at the first hit (ShapeKDTree::rayIntersect(ray)); else closest hit.
  * COUNT    : accumulate visited nodes / tested triangles (the N_nodes, N_tris of the roofline formula).
@@ -116,104 +229,11 @@ template <bool ANY> __device__ __forceinline__ float adaptiveMinT(float mint, fl
 template <bool ANY, bool COUNT, bool PROJ, int STACK, int BLOCK>
 __device__ __forceinline__ DHit traverse(const Node4 *__restrict__ nodes, const void *__restrict__ tris,
                                          const DRay &ray, uint32_t *sstack, uint32_t &nNodes, uint32_t &nTris) {
-    DHit hit; hit.t = kInf; hit.u = 0.f; hit.v = 0.f; hit.id = kNoHit;
-    const float ox = ray.ox, oy = ray.oy, oz = ray.oz;
-    const float tmin = adaptiveMinT<ANY>(ray.mint, ox, oy, oz);
-    float tmax = ray.maxt;
-    /* A zero direction component would give 1/d = inf and 0 * inf = NaN for an origin lying exactly on a slab plane
-     * (rays aimed along an axis at mesh vertices do that); a huge finite reciprocal keeps such a slab "inside". */
-    const float kBig = 0x1p100f, kTiny = 0x1p-100f;
-    const float idx = fabsf(ray.dx) < kTiny ? copysignf(kBig, ray.dx) : 1.0f / ray.dx;
-    const float idy = fabsf(ray.dy) < kTiny ? copysignf(kBig, ray.dy) : 1.0f / ray.dy;
-    const float idz = fabsf(ray.dz) < kTiny ? copysignf(kBig, ray.dz) : 1.0f / ray.dz;
-    const bool negx = idx < 0.f, negy = idy < 0.f, negz = idz < 0.f;
-    WoopRay wr; wr.init(ray.dx, ray.dy, ray.dz);
-    const uint4 *nodes4 = reinterpret_cast<const uint4 *>(nodes);
-    const float4 *tris4 = reinterpret_cast<const float4 *>(tris);
-    const int tid = threadIdx.x;
+    Walk<ANY, COUNT, PROJ, STACK, BLOCK> w;
     uint32_t ovf[kStackOverflow];
-    int sp = 0;
-#define KKD_PUSH(V) { if (sp < STACK) sstack[sp * BLOCK + tid] = (V); else ovf[sp - STACK] = (V); ++sp; }
-/* the LDS read is unconditional and the private read a separate, rarely taken branch: one select between the two
- * pointers would turn every pop into a flat load, which goes the long way round through the texture addresser */
-#define KKD_POP() { if (sp == 0) cur = kTraversalDone; else { --sp; cur = sstack[(sp < STACK ? sp : STACK - 1) * BLOCK + tid]; \
-                    if (sp >= STACK) cur = ovf[sp - STACK]; } }
-    /* cur: inner node index | leaf reference (kLeafBit) | kTraversalDone */
-    uint32_t cur = (tmax > tmin) ? 0u : kTraversalDone;
-    /* One step per iteration and lane: a node visit or ONE triangle test, so a lane at a leaf and a lane at a node both
-     * make progress and the iteration costs one node visit plus one triangle test, not the longest leaf of the wave.
-     * (Measured and rejected: parking lanes at leaves until N of them can be tested together -- fewer load instructions,
-     * more iterations, 4-20% slower for N = 8..48; and refilling idle lanes from a per-wave ray queue -- 84 VGPRs, slower.)
-     * Every wave leaves this loop: the walk is finite on a tree, and the step bound ends it on a malformed one. */
-    for (int guard = 1 << 24; guard > 0; --guard) {
-        const bool atNode = !(cur & kLeafBit);
-        const bool atLeaf = !atNode && cur != kTraversalDone;
-        const unsigned long long leafLanes = __ballot(atLeaf);
-        const bool anyNode = __ballot(atNode) != 0ull;
-        if (!anyNode && leafLanes == 0ull) break;
-        if (atNode) {
-            if (COUNT) ++nNodes;
-            const uint4 *n = nodes4 + (size_t)cur * 4;
-            const uint4 hd = n[0], ch = n[1], qa = n[2], qb = n[3];
-            const float gx = __uint_as_float(hd.x), gy = __uint_as_float(hd.y), gz = __uint_as_float(hd.z);
-            const float sx = __uint_as_float((hd.w & 0xffu) << 23), sy = __uint_as_float(((hd.w >> 8) & 0xffu) << 23),
-                        sz = __uint_as_float(((hd.w >> 16) & 0xffu) << 23);
-            float d0, d1, d2, d3;
-            /* Slab test in the node's grid: t(plane q) = (origin + q * scale - o) / d = q * ta + tb, so a plane costs one
-             * byte->float conversion and one fma.  The near / far plane of each axis is picked by the sign of the ray
-             * direction for all four children at once (one select of the packed byte quadruple).  The 1e-6 slack on
-             * both sides covers the rounding of ta, tb (the builder's enclosure check covers the grid itself). */
-            const float tax = sx * idx, tay = sy * idy, taz = sz * idz;
-            const float tbx = (gx - ox) * idx, tby = (gy - oy) * idy, tbz = (gz - oz) * idz;
-            const uint32_t nx4 = negx ? qa.w : qa.x, fx4 = negx ? qa.x : qa.w;
-            const uint32_t ny4 = negy ? qb.x : qa.y, fy4 = negy ? qa.y : qb.x;
-            const uint32_t nz4 = negz ? qb.y : qa.z, fz4 = negz ? qa.z : qb.y;
-#define KKD_SLAB(D, K, C) { \
-            const float tnx = fmaf((float)((nx4 >> (8 * K)) & 0xffu), tax, tbx), tfx = fmaf((float)((fx4 >> (8 * K)) & 0xffu), tax, tbx); \
-            const float tny = fmaf((float)((ny4 >> (8 * K)) & 0xffu), tay, tby), tfy = fmaf((float)((fy4 >> (8 * K)) & 0xffu), tay, tby); \
-            const float tnz = fmaf((float)((nz4 >> (8 * K)) & 0xffu), taz, tbz), tfz = fmaf((float)((fz4 >> (8 * K)) & 0xffu), taz, tbz); \
-            const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin)); \
-            const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tmax)); \
-            D = (tn * 0.999999f <= tf * 1.000001f && (C) != 0u) ? tn : kInf; }
-            KKD_SLAB(d0, 0, ch.x)
-            KKD_SLAB(d1, 1, ch.y)
-            KKD_SLAB(d2, 2, ch.z)
-            KKD_SLAB(d3, 3, ch.w)
-#undef KKD_SLAB
-            uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
-#define KKD_CSWAP(DA, CA, DB, CB) { const bool s = DB < DA; const float td = s ? DB : DA; DB = s ? DA : DB; DA = td; \
-                                    const uint32_t tc = s ? CB : CA; CB = s ? CA : CB; CA = tc; }
-            KKD_CSWAP(d0, c0, d1, c1) KKD_CSWAP(d2, c2, d3, c3) KKD_CSWAP(d0, c0, d2, c2) KKD_CSWAP(d1, c1, d3, c3) KKD_CSWAP(d1, c1, d2, c2)
-#undef KKD_CSWAP
-            if (d0 < kInf) {
-                if (d3 < kInf) KKD_PUSH(c3)
-                if (d2 < kInf) KKD_PUSH(c2)
-                if (d1 < kInf) KKD_PUSH(c1)
-                cur = c0;
-            } else KKD_POP()
-        }
-        {
-            if (atLeaf) {
-                const uint32_t slot = cur & kLeafStartMask;
-                if (COUNT) ++nTris;
-                const float4 *tp = tris4 + (size_t)slot * 3;
-                const float4 a = tp[0], b = tp[1], c = tp[2];
-                float t, u, v;
-                bool done = false;
-                if (PROJ ? projIntersect(ox, oy, oz, ray.dx, ray.dy, ray.dz, a, b, c, tmin, tmax, t, u, v)
-                         : woopIntersect(wr, ox, oy, oz, a, b, c, tmin, tmax, t, u, v)) {
-                    tmax = t; hit.t = t; hit.u = u; hit.v = v; hit.id = slot;
-                    done = ANY;
-                }
-                if (done) cur = kTraversalDone;
-                else if (cur & (7u << 28)) cur = cur - (1u << 28) + 1u;   /* next triangle of this leaf */
-                else KKD_POP()
-            }
-        }
-    }
-#undef KKD_PUSH
-#undef KKD_POP
-    return hit;
+    w.begin(ray);
+    w.run(nodes, tris, sstack, ovf, nNodes, nTris, 1 << 24);
+    return w.hit;
 }
 
 /*
