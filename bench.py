@@ -164,7 +164,9 @@ def main():
                 traffic = json.load(open(tpath)).get(args.workload, {}).get(abi.STAGE_NAMES[dom])
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": abi.STAGE_NAMES[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        kernel_note = {"bsdf": "bsdf = kTraceRound<closest> (first round + resume round: 2 launches per batch, averaged)",
+                       "shadow": "shadow = kTraceRound<any> (first round + resume round: 2 launches per batch, averaged)"}
+        roofline = {"bound": "hbm", "kernel": kernel_note.get(abi.STAGE_NAMES[dom], abi.STAGE_NAMES[dom]), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     # algorithmic bytes count every node / triangle visit; the visits are served by L1/L2, so the
                     # figure can exceed the HBM peak -- the measured HBM side of the same launch is reported beside it

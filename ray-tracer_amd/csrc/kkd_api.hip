@@ -417,7 +417,8 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         /* all nB planes are contiguous when count == stride; otherwise trace plane by plane */
         auto trace = [&](const DRay *rays, uint64_t n, bool any, void *out, int cls) {
             TraceContinuation c = cont; c.iterCap = any ? capAny : capClosest;
-            if (c.iterCap > 0) launchTracePhased(st, ctx->ds, rays, n, any, count, out, ctr, cls, c);
+            /* stage_launches counts kernel launches: a traversal in rounds is cont.rounds kernels */
+            if (c.iterCap > 0) { launchTracePhased(st, ctx->ds, rays, n, any, count, out, ctr, cls, c); launches[any ? KKD_STAGE_SHADOW : KKD_STAGE_BSDF] += std::max(2, c.rounds) - 1; }
             else launchTrace(st, ctx->ds, rays, n, any, count, any ? 2 : 0, out, ctr, cls);
         };
         if (bp.count == bp.stride) { trace(wb.bsdfRays, (uint64_t)S * nB, false, wb.bsdfHits, KKD_RAYS_BSDF); launches[KKD_STAGE_BSDF]++; }
