@@ -1,0 +1,76 @@
+"""Round-based traversal (kTraceRound) under stress, on the GPU: tiny iteration caps and several rounds (almost every ray is
+parked, shards overflow, parked rays are parked again), and stacks that spill into private memory (such lanes must not be
+parked).  The caps are read from the environment once per process, so the stress configuration runs in ONE child process."""
+import json
+import os
+import subprocess
+import sys
+import numpy as np
+import pytest
+import kkoracle
+from kkdirect import Scene, scenes
+import helpers
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import json, sys, os
+sys.path[:0] = [os.path.join(%(root)r, "ray-tracer_amd"), os.path.join(%(root)r, "oracle"), os.path.join(%(root)r, "tests")]
+import numpy as np, kkdirect, kkoracle, helpers
+from kkdirect import scenes
+from test_gpu_parity import _material_scene
+out = {}
+for name, sc, spp, kw in (("cornell", scenes.cornell_box(96, 96), 16, {}), ("materials", _material_scene(64, 48), 16, dict(bsdf_samples=2, light_samples=2)),
+                          ("sponza", scenes.sponza_class(96, 54, target_tris=20000), 8, {})):
+    ref, so = kkoracle.Oracle(sc).render(spp, seed=1, **kw)
+    with kkdirect.Context(device=0, seed=1, max_samples_in_flight=%(batch)d).upload(sc) as ctx:
+        film, sg = ctx.render(spp, **kw)
+    out[name] = dict(relmse=helpers.rel_mse(helpers.develop(film), helpers.develop(ref)), samples=[int(sg.samples), int(so.samples)],
+                     closest=[int(sg.rays_closest), int(so.rays_closest)], finite=bool(np.isfinite(film).all()))
+print("RESULT " + json.dumps(out))
+"""
+
+
+@pytest.mark.parametrize("env", [dict(KKD_ITER_CAP_CLOSEST="3", KKD_ITER_CAP_ANY="2", KKD_ITER_CAP_LATER="2", KKD_TRACE_ROUNDS="5"),
+                                 dict(KKD_ITER_CAP_CLOSEST="9", KKD_ITER_CAP_ANY="7", KKD_ITER_CAP_LATER="5", KKD_TRACE_ROUNDS="3"),
+                                 dict(KKD_ITER_CAP_CLOSEST="0", KKD_ITER_CAP_ANY="0")])
+def test_rounds_under_stress_give_the_same_image(gpu, env):
+    e = dict(os.environ); e.update(env)
+    p = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT, batch=65536)], env=e, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    for name, r in res.items():
+        assert r["finite"] and r["samples"][0] == r["samples"][1] and r["closest"][0] == r["closest"][1], (name, r)
+        assert r["relmse"] < (1e-5 if name == "cornell" else 2e-4), (name, r)
+
+
+def test_deep_stacks_spill_and_are_not_parked(gpu):
+    """20 000 coincident triangles: the builder can only halve the range, the tree is as deep as it gets and every ray that
+    hits the triangle hits every box, so the per-lane stack grows past its 16 LDS words into the private part."""
+    n = 20000
+    tri = np.array([[-1, 0, -1], [1, 0, -1], [0, 0, 1.5]], np.float32)
+    pos = np.tile(tri, (n, 1)); idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    sc = Scene(); sc.add_mesh(pos, idx, sc.diffuse())
+    sc.add_mesh([[-3, 2, -3], [-3, 2, 3], [3, 2, 3], [3, 2, -3]], [[0, 2, 1], [0, 3, 2]], sc.diffuse((0, 0, 0)), radiance=(5, 5, 5))
+    sc.set_sensor(np.eye(4), 45, 16, 16)
+    o = kkoracle.Oracle(sc)
+    rng = np.random.RandomState(3)
+    rays = np.zeros((2000, 8), np.float32)
+    rays[:, 0:3] = rng.uniform(-1.5, 1.5, (2000, 3)) + [0, 3, 0]; rays[:, 1] = 1.0
+    tgt = rng.uniform(-1.2, 1.2, (2000, 3)); tgt[:, 1] = 0
+    d = tgt - rays[:, 0:3]; rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True); rays[:, 7] = np.inf
+    with gpu.Context(device=0).upload(sc) as ctx:
+        assert ctx.accel_info()["n_leaf_tris"] == n + 2
+        a, b = o.trace(rays), ctx.trace(rays)
+        hit_a, hit_b = a["prim"] != 0xFFFFFFFF, b["prim"] != 0xFFFFFFFF
+        assert (hit_a != hit_b).mean() < 2e-3                       # rays through the outline of the triangle
+        both = hit_a & hit_b
+        assert both.sum() > 500
+        np.testing.assert_allclose(b["t"][both], a["t"][both], rtol=1e-5)
+        assert (b["prim"][both] < n).all() and (a["prim"][both] < n).all()      # some copy of the stacked triangle: equal-distance tie
+        sa, sb = o.trace(rays, any_hit=True), ctx.trace(rays, any_hit=True)
+        assert ((sa["prim"] != 0xFFFFFFFF) != (sb["prim"] != 0xFFFFFFFF)).mean() < 2e-3
+        film, st = ctx.render(4)                                   # and through the round-based render path
+        ref, _ = o.render(4, seed=1)
+    assert helpers.rel_mse(helpers.develop(film), helpers.develop(ref)) < 1e-4
