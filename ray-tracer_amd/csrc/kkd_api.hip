@@ -50,6 +50,8 @@ struct kkd_ctx {
            envTexels, envCdfRows, envCdfCols, envRowWeights;
     /* work buffers */
     DevBuf contRecs, contStacks, contCount;
+    /* first-round step budgets of the round-based traversal; adapted from the share of rays the last batch parked */
+    int capClosest = 28, capAny = 20;
     DevBuf hits, accum, refN, bsdfRays, bsdfHits, brec0, shadowRays, occluded, lrec, film, counters, apiRays, apiHits;
     std::vector<hipEvent_t> events;
 };
@@ -233,6 +235,7 @@ static DeviceCounters sumShards(const std::vector<DeviceCounters> &shards) {
     DeviceCounters c; std::memset(&c, 0, sizeof(c));
     for (const DeviceCounters &s : shards) {
         c.samples += s.samples;
+        for (int k = 0; k < 3; ++k) c.parked[k] += s.parked[k];
         for (int k = 0; k < 3; ++k) { c.rays[k] += s.rays[k]; c.nodes[k] += s.nodes[k]; c.tris[k] += s.tris[k]; }
     }
     return c;
@@ -354,10 +357,12 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     need(ctx->hits, S * sizeof(DHit)); need(ctx->accum, S * 16); need(ctx->refN, S * 16);
     need(ctx->bsdfRays, S * nB * sizeof(DRay)); need(ctx->bsdfHits, S * nB * sizeof(DHit)); need(ctx->brec0, S * nB * 16);
     /* continuation buffer of the two-launch traversal: a quarter of the largest ray launch may be parked */
-    static const int capClosest = [] { const char *e = getenv("KKD_ITER_CAP_CLOSEST"); return e ? atoi(e) : 28; }();
-    static const int capAny = [] { const char *e = getenv("KKD_ITER_CAP_ANY"); return e ? atoi(e) : 20; }();
+    /* $KKD_ITER_CAP_CLOSEST / _ANY pin the budgets (0 = one launch, no rounds); else they adapt, see below */
+    static const int envCapClosest = [] { const char *e = getenv("KKD_ITER_CAP_CLOSEST"); return e ? atoi(e) : -1; }();
+    static const int envCapAny = [] { const char *e = getenv("KKD_ITER_CAP_ANY"); return e ? atoi(e) : -1; }();
+    const int capClosest = envCapClosest >= 0 ? envCapClosest : ctx->capClosest, capAny = envCapAny >= 0 ? envCapAny : ctx->capAny;
     const uint64_t contCap = std::min<uint64_t>(((uint64_t)S * std::max(nB, nL) / 2 / kContShards + 128) * kContShards, 0x7fffffffull);   /* two halves of n/4 records */
-    need(ctx->contRecs, contCap * sizeof(ContRec)); need(ctx->contStacks, contCap * 16 * sizeof(uint32_t)); need(ctx->contCount, 2 * kContShards * 32 * sizeof(uint32_t));
+    need(ctx->contRecs, contCap * sizeof(ContRec)); need(ctx->contStacks, contCap * 16 * sizeof(uint32_t)); need(ctx->contCount, 4 * kContShards * 32 * sizeof(uint32_t));   /* closest: 2 ping-pong counter arrays, any: 2 */
     need(ctx->shadowRays, S * nL * sizeof(DRay)); need(ctx->occluded, S * nL * 4); need(ctx->lrec, S * nL * 16);
     need(ctx->counters, kCounterShards * sizeof(DeviceCounters));
     if (!devFilm) need(ctx->film, (size_t)W * H * 5 * sizeof(float));
@@ -417,6 +422,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         /* all nB planes are contiguous when count == stride; otherwise trace plane by plane */
         auto trace = [&](const DRay *rays, uint64_t n, bool any, void *out, int cls) {
             TraceContinuation c = cont; c.iterCap = any ? capAny : capClosest;
+            c.count = cont.count + (any ? 2u : 0u) * kContShards * 32u;
             /* stage_launches counts kernel launches: a traversal in rounds is cont.rounds kernels */
             if (c.iterCap > 0) { launchTracePhased(st, ctx->ds, rays, n, any, count, out, ctr, cls, c); launches[any ? KKD_STAGE_SHADOW : KKD_STAGE_BSDF] += std::max(2, c.rounds) - 1; }
             else launchTrace(st, ctx->ds, rays, n, any, count, any ? 2 : 0, out, ctr, cls);
@@ -436,6 +442,19 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     KKD_HIP(ctx, hipMemcpyAsync(shards.data(), ctr, kCounterShards * sizeof(DeviceCounters), hipMemcpyDeviceToHost, st));
     KKD_HIP(ctx, hipStreamSynchronize(st));
     const DeviceCounters c = sumShards(shards);
+    {
+        /* Budget control over the whole render: too many parked rays and the second round repeats their set-up for
+         * nothing, too few and the first round idles in its tail.  On C2 and C4 the best fixed budgets park 8-16 % of the traced rays. */
+        auto adapt = [&](int &cap, int used, int envCap, int cls) {
+            if (used <= 0 || c.rays[cls] < (1u << 16)) return;
+            const double f = (double)c.parked[cls] / (double)c.rays[cls];
+            if (envCap < 0) { if (f > 0.15) cap = std::min(64, cap + 2); else if (f < 0.06) cap = std::max(12, cap - 2); }
+            static const bool dbg = getenv("KKD_DEBUG_ROUNDS") != nullptr;
+            if (dbg) fprintf(stderr, "rounds: class %d budget %d parked %.3f -> budget %d\n", cls, used, f, envCap < 0 ? cap : used);
+        };
+        adapt(ctx->capClosest, capClosest, envCapClosest, KKD_RAYS_BSDF);
+        adapt(ctx->capAny, capAny, envCapAny, KKD_RAYS_SHADOW);
+    }
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         float ms = 0.f;

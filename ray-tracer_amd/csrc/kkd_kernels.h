@@ -12,7 +12,7 @@ static constexpr int kMaxTraversalStack = 16 + 80;
 /* One word takes only ~88 M atomic adds per second, far fewer than the waves a render retires, so the counters are
  * sharded: a wave adds into shard (blockIdx.x % kCounterShards), each shard on its own 128-byte line; the host sums. */
 static constexpr int kCounterShards = 1024;
-struct alignas(128) DeviceCounters { unsigned long long samples, pad; unsigned long long rays[3], nodes[3], tris[3]; unsigned long long pad2[5]; };
+struct alignas(128) DeviceCounters { unsigned long long samples, pad; unsigned long long rays[3], nodes[3], tris[3]; unsigned long long parked[3]; /* rays the first traversal round parked, per class */ unsigned long long pad2[2]; };
 
 /* One batch = work items [w0, w0 + count) of the render; see mapWorkItem() in kkd_kernels.hip. */
 struct BatchParams {

@@ -190,7 +190,10 @@ __global__ void __launch_bounds__(BLOCK, 8) kTraceRound(const Node4 *__restrict_
             uint32_t base = 0;
             if (m != 0ull) {
                 const int leader = __ffsll((long long)m) - 1;
-                if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(next.count + shard * 32u, (uint32_t)__popcll(m));
+                if ((int)(threadIdx.x & 63) == leader) {
+                    base = atomicAdd(next.count + shard * 32u, (uint32_t)__popcll(m));
+                    if (FIRST && ctr) atomicAdd(&counterShard(ctr)->parked[cls], (unsigned long long)__popcll(m));
+                }
                 base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
             }
             const uint32_t rank = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -549,7 +552,7 @@ static void launchPhasedT(hipStream_t st, const DScene &sc, const DRay *rays, ui
     bufs[0].perShard = bufs[1].perShard = half;
     bufs[1].recs = cont.recs + (size_t)kContShards * half; bufs[1].stacks = cont.stacks + (size_t)kContShards * half * (kStackLds / 4);
     bufs[1].count = cont.count + kContShards * 32;
-    hipMemsetAsync(cont.count, 0, 2 * kContShards * 32 * sizeof(uint32_t), st);
+    hipMemsetAsync(cont.count, 0, 2 * kContShards * 32 * sizeof(uint32_t), st);   /* both ping-pong counter arrays of this ray kind */
     const int rounds = cont.rounds < 2 ? 2 : cont.rounds;
     /* a shard cannot hold more than its share of the rays of this launch */
     const uint64_t perShardMax = std::min<uint64_t>(half, (n + kContShards - 1) / kContShards + 256);
