@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(256, 4) kShade(DScene sc, BatchParams bp, Wave
     wb.accum[i] = accum;
 }
 
-/* ---- filtered splat of 64 samples of one pixel (ImageBlock::put, reduced across the wave) -----------------------
+/* ---- filtered splat of the G samples a lane group holds of one pixel (ImageBlock::put, reduced across the group) -----------------------
  * Every lane holds one sample of pixel (X, Y); its footprint lies inside the (2B+1)^2 window around the pixel, i.e.
  * NV = (2B+1)^2 * 5 film words.  The words are summed over the 64 lanes by a halving butterfly: at each of the six
  * steps a lane hands one half of the words it still holds to a partner and adds the partner's other half, so 64 words
@@ -340,10 +340,12 @@ template <int N, int CTRL> __device__ __forceinline__ void butterflyDpp(float *a
     }
 }
 
-template <int B>
-__device__ __forceinline__ void splatWave64(float *__restrict__ film, const float *sfilter, float radius, float scale,
-                                            int X, int Y, int W, int H, float posx, float posy, const float *val, bool noAtomics) {
-    constexpr int WIN = 2 * B + 1, NV = WIN * WIN * 5, NPASS = (NV + 63) / 64;
+/* G = lanes per pixel (a power of two, 8..64): the butterfly starts at the stage that halves a G-lane group, every group
+ * of the wave reduces its own pixel's window and lane l of a group ends up owning word (pass * G + l). */
+template <int B, int G>
+__device__ __forceinline__ void splatGroup(float *__restrict__ film, const float *sfilter, float radius, float scale,
+                                           int X, int Y, int W, int H, float posx, float posy, const float *val, bool noAtomics) {
+    constexpr int WIN = 2 * B + 1, NV = WIN * WIN * 5, NPASS = (NV + G - 1) / G;
     const int lane = threadIdx.x & 63;
     const int lox = (int)ceilf(posx - radius), hix = (int)floorf(posx + radius);
     const int loy = (int)ceilf(posy - radius), hiy = (int)floorf(posy + radius);
@@ -356,21 +358,25 @@ __device__ __forceinline__ void splatWave64(float *__restrict__ film, const floa
     }
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
-        float a[64];
+        float a[G];
 #pragma unroll
-        for (int i = 0; i < 64; ++i) {
-            const int k = pass * 64 + i;
+        for (int i = 0; i < G; ++i) {
+            const int k = pass * G + i;
             a[i] = k < NV ? fx[(k / 5) % WIN] * fy[(k / 5) / WIN] * val[k % 5] : 0.f;
         }
+        if (G >= 64) {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) { swap32(a[i], a[i + 32]); a[i] += a[i + 32]; }
+            for (int i = 0; i < 32; ++i) { swap32(a[i], a[i + 32]); a[i] += a[i + 32]; }
+        }
+        if (G >= 32) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { swap16(a[i], a[i + 16]); a[i] += a[i + 16]; }
-        butterflyDpp<8, 0x140>(a, (lane & 8) != 0);   /* row_mirror: partner differs in bit 3          */
-        butterflyDpp<4, 0x141>(a, (lane & 4) != 0);   /* row_half_mirror: partner differs in bit 2     */
-        butterflyDpp<2, 0x4E>(a, (lane & 2) != 0);    /* quad_perm [2,3,0,1]                           */
-        butterflyDpp<1, 0xB1>(a, (lane & 1) != 0);    /* quad_perm [1,0,3,2]                           */
-        const int k = pass * 64 + lane;
+            for (int i = 0; i < 16; ++i) { swap16(a[i], a[i + 16]); a[i] += a[i + 16]; }
+        }
+        if (G >= 16) butterflyDpp<8, 0x140>(a, (lane & 8) != 0);   /* row_mirror: partner differs in bit 3          */
+        butterflyDpp<4, 0x141>(a, (lane & 4) != 0);                /* row_half_mirror: partner differs in bit 2     */
+        butterflyDpp<2, 0x4E>(a, (lane & 2) != 0);                 /* quad_perm [2,3,0,1]                           */
+        butterflyDpp<1, 0xB1>(a, (lane & 1) != 0);                 /* quad_perm [1,0,3,2]                           */
+        const int k = pass * G + (lane & (G - 1));
         if (k < NV && a[0] != 0.f) {
             const int c = k % 5, pix = k / 5, xo = X - B + pix % WIN, yo = Y - B + pix / WIN;
             if (xo >= 0 && xo < W && yo >= 0 && yo < H) { if (!noAtomics) atomicAdd(film + ((size_t)yo * W + xo) * 5 + c, a[0]); else if (a[0] == 12345.678f) film[0] = a[0]; }
@@ -442,13 +448,20 @@ __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveB
     const uint32_t g = bp.g, j = threadIdx.x & (g - 1u);
     /* every lane of a group maps to the same pixel, also the inactive ones */
     const int X = s.X, Y = s.Y, W = bp.W, H = bp.H;
-    if (g == 64u && b <= 3) {   /* wave-uniform: the whole wave holds samples of one pixel */
+    if (g >= 8u && b <= 3) {   /* wave-uniform: groups of g lanes hold the samples of one pixel each */
+        const bool na = (bp.debug & 1u) != 0;
+#define KKD_SPLAT(BB) switch (g) { \
+            case 64u: splatGroup<BB, 64>(film, sfilter, radius, scale, X, Y, W, H, posx, posy, val, na); break; \
+            case 32u: splatGroup<BB, 32>(film, sfilter, radius, scale, X, Y, W, H, posx, posy, val, na); break; \
+            case 16u: splatGroup<BB, 16>(film, sfilter, radius, scale, X, Y, W, H, posx, posy, val, na); break; \
+            default: splatGroup<BB, 8>(film, sfilter, radius, scale, X, Y, W, H, posx, posy, val, na); break; }
         switch (b) {
-            case 0: splatWave64<0>(film, sfilter, radius, scale, X, Y, W, H, posx, posy, val, (bp.debug & 1u) != 0); break;
-            case 1: splatWave64<1>(film, sfilter, radius, scale, X, Y, W, H, posx, posy, val, (bp.debug & 1u) != 0); break;
-            case 2: splatWave64<2>(film, sfilter, radius, scale, X, Y, W, H, posx, posy, val, (bp.debug & 1u) != 0); break;
-            default: splatWave64<3>(film, sfilter, radius, scale, X, Y, W, H, posx, posy, val, (bp.debug & 1u) != 0); break;
+            case 0: KKD_SPLAT(0) break;
+            case 1: KKD_SPLAT(1) break;
+            case 2: KKD_SPLAT(2) break;
+            default: KKD_SPLAT(3) break;
         }
+#undef KKD_SPLAT
         if (ctr) countRays(s.active, &counterShard(ctr)->samples);
         return;
     }
