@@ -318,6 +318,17 @@ int kkd_write_pfm(const char *path, const float *pixels, uint32_t width, uint32_
  * cnpy::npy_save writes it.  Host only, no context needed. */
 int kkd_write_npy(const char *path, const float *pixels, uint32_t width, uint32_t height, uint32_t channels);
 
+/* ---- parameter extraction for the Mitsuba-side adapter ---- */
+
+/* Decodes the byte stream InstanceManager::serialize(stream, bsdf) writes (src/libcore/serialization.cpp:73-87) for
+ * the BSDFs of this path -- SmoothDiffuse (src/bsdfs/diffuse.cpp:161-165), RoughConductor (roughconductor.cpp:216-226),
+ * RoughPlastic (roughplastic.cpp:243-253), SmoothDielectric (dielectric.cpp:176-182), TwoSidedBRDF (twosided.cpp:77-82)
+ * with constant textures (src/libhw/basicshader.cpp:29-49) -- into kkd_material blocks, nested BSDFs as further
+ * entries.  Several BSDFs serialised one after the other with the same InstanceManager share sub-objects by id and
+ * are parsed in one call; the k-th top-level BSDF is the first entry not referenced as `nested` before it.  Host
+ * only; errors through kkd_last_error(NULL). */
+int kkd_parse_bsdf_stream(const void *bytes, uint64_t n_bytes, kkd_material *out, uint32_t capacity, uint32_t *count);
+
 /* ---- on-disk mesh formats: the step right before the path ---- */
 
 #define KKD_MESH_FACE_NORMALS 1u   /* TriMesh::m_faceNormals: shade with face normals (EFaceNormals, src/librender/trimesh.cpp:93) */

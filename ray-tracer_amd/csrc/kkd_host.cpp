@@ -17,6 +17,7 @@
  */
 #include "kkd_host.h"
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -542,3 +543,107 @@ int kkd_write_npy(const char *path, const float *pixels, uint32_t width, uint32_
 }
 
 } /* extern "C" */
+
+/* ---- BSDF parameter extraction for the Mitsuba-side adapter (host only) -------------------------------------------
+ * The adapter cannot reach into a BSDF plugin, but it can serialise it: InstanceManager::serialize(stream, bsdf)
+ * (src/libcore/serialization.cpp:73-87) writes [uint32 id][class name, NUL-terminated][body] for a new object, the id
+ * alone for one already written, 0 for NULL.  Bodies (little endian, Float = float32, Spectrum = 3 floats):
+ *   BSDF base                 bool ensureEnergyConservation                       src/librender/bsdf.cpp:43-46
+ *   SmoothDiffuse             base, Texture reflectance                           src/bsdfs/diffuse.cpp:161-165
+ *   RoughConductor            base, uint type, bool sampleVisible, Texture alphaU, alphaV, specularReflectance,
+ *                             Spectrum eta, Spectrum k                            src/bsdfs/roughconductor.cpp:216-226
+ *   RoughPlastic              base, uint type, bool sampleVisible, Texture specularReflectance, diffuseReflectance,
+ *                             alpha, float eta, bool nonlinear                    src/bsdfs/roughplastic.cpp:243-253
+ *   SmoothDielectric          base, float eta, Texture specularReflectance, specularTransmittance
+ *                                                                                 src/bsdfs/dielectric.cpp:176-182
+ *   TwoSidedBRDF              base, BSDF nested[0], BSDF nested[1]                src/bsdfs/twosided.cpp:77-82
+ *   ConstantSpectrumTexture   Spectrum value;  ConstantFloatTexture  float value  src/libhw/basicshader.cpp:29-49
+ * Any other class (bitmap textures, other BSDFs) is rejected: the device path takes constant parameters only. */
+namespace {
+struct BsdfStream {
+    const uint8_t *p, *end; std::string err;
+    std::map<uint32_t, int> bsdfOfId;                 /* serialisation id -> index in out[] */
+    std::map<uint32_t, std::array<float, 3>> texOfId; /* constant textures already seen     */
+    kkd_material *out; uint32_t cap, n = 0;
+    bool take(void *dst, size_t k) { if ((size_t)(end - p) < k) { err = "BSDF stream: truncated"; return false; } std::memcpy(dst, p, k); p += k; return true; }
+    bool u32(uint32_t &v) { return take(&v, 4); }
+    bool f32(float &v) { return take(&v, 4); }
+    bool b8(bool &v) { uint8_t c; if (!take(&c, 1)) return false; v = c != 0; return true; }
+    bool str(std::string &s) { s.clear(); while (p < end && *p) s.push_back((char)*p++); if (p >= end) { err = "BSDF stream: unterminated class name"; return false; } ++p; return true; }
+    bool texture(float rgb[3]) {
+        uint32_t id; if (!u32(id)) return false;
+        if (id == 0) { err = "BSDF stream: missing texture"; return false; }
+        auto it = texOfId.find(id);
+        if (it != texOfId.end()) { for (int k = 0; k < 3; ++k) rgb[k] = it->second[k]; return true; }
+        std::string cls; if (!str(cls)) return false;
+        std::array<float, 3> v;
+        if (cls == "ConstantSpectrumTexture") { if (!take(v.data(), 12)) return false; }
+        else if (cls == "ConstantFloatTexture") { float f; if (!f32(f)) return false; v = { f, f, f }; }
+        else { err = "BSDF stream: texture class \"" + cls + "\" is not constant"; return false; }
+        texOfId[id] = v; for (int k = 0; k < 3; ++k) rgb[k] = v[k];
+        return true;
+    }
+    /* returns the material index or -1 */
+    int bsdf(bool allowNull) {
+        uint32_t id; if (!u32(id)) return -1;
+        if (id == 0) { if (!allowNull) err = "BSDF stream: missing BSDF"; return -1; }
+        auto it = bsdfOfId.find(id);
+        if (it != bsdfOfId.end()) return it->second;
+        std::string cls; if (!str(cls)) return -1;
+        if (n >= cap) { err = "BSDF stream: more materials than the output array holds"; return -1; }
+        const int me = (int)n++;
+        bsdfOfId[id] = me;
+        kkd_material m; std::memset(&m, 0, sizeof(m));
+        m.sample_visible = 1; m.nested[0] = m.nested[1] = -1;
+        for (int k = 0; k < 3; ++k) { m.specular_reflectance[k] = 1.f; m.specular_transmittance[k] = 1.f; }
+        bool ec;
+        if (!b8(ec)) return -1;                                   /* BSDF::serialize */
+        uint32_t type; bool sv; float a[3];
+        if (cls == "SmoothDiffuse") {
+            m.type = KKD_BSDF_DIFFUSE;
+            if (!texture(m.reflectance)) return -1;
+        } else if (cls == "RoughConductor") {
+            m.type = KKD_BSDF_ROUGHCONDUCTOR;
+            if (!u32(type) || !b8(sv)) return -1;
+            m.distribution = (int32_t)type; m.sample_visible = sv;
+            if (!texture(a)) return -1;
+            m.alpha_u = a[0];
+            if (!texture(a)) return -1;
+            m.alpha_v = a[0];
+            if (!texture(m.specular_reflectance) || !take(m.cond_eta, 12) || !take(m.cond_k, 12)) return -1;
+        } else if (cls == "RoughPlastic") {
+            m.type = KKD_BSDF_ROUGHPLASTIC;
+            if (!u32(type) || !b8(sv)) return -1;
+            m.distribution = (int32_t)type; m.sample_visible = sv;
+            if (!texture(m.specular_reflectance) || !texture(m.reflectance) || !texture(a)) return -1;
+            m.alpha_u = m.alpha_v = a[0];
+            bool nl; if (!f32(m.eta) || !b8(nl)) return -1;
+            m.nonlinear = nl;
+        } else if (cls == "SmoothDielectric") {
+            m.type = KKD_BSDF_DIELECTRIC;
+            if (!f32(m.eta) || !texture(m.specular_reflectance) || !texture(m.specular_transmittance)) return -1;
+        } else if (cls == "TwoSidedBRDF") {
+            m.type = KKD_BSDF_TWOSIDED;
+            out[me] = m;                                          /* reserve the slot before the children take theirs */
+            const int n0 = bsdf(false); if (n0 < 0) return -1;
+            const int n1 = bsdf(true); if (n1 < 0 && !err.empty()) return -1;
+            m.nested[0] = n0; m.nested[1] = n1;
+        } else { err = "BSDF stream: BSDF class \"" + cls + "\" is not on the kk direct path"; return -1; }
+        if (m.distribution < 0 || m.distribution > KKD_DISTR_PHONG) { err = "BSDF stream: unknown microfacet distribution"; return -1; }
+        out[me] = m;
+        return me;
+    }
+};
+} /* namespace */
+
+extern "C" int kkd_parse_bsdf_stream(const void *bytes, uint64_t n_bytes, kkd_material *out, uint32_t capacity, uint32_t *count) {
+    if (!bytes || !out || !count) { kkd::g_globalError = "kkd_parse_bsdf_stream: null argument"; return KKD_ERR_INVALID; }
+    BsdfStream s{ (const uint8_t *)bytes, (const uint8_t *)bytes + n_bytes, std::string(), {}, {}, out, capacity };
+    *count = 0;
+    /* the stream may hold several top-level BSDFs in a row (one InstanceManager for the whole scene): parse to the end */
+    while (s.p < s.end) {
+        if (s.bsdf(false) < 0) { kkd::g_globalError = s.err.empty() ? "BSDF stream: malformed" : s.err; return KKD_ERR_INVALID; }
+    }
+    *count = s.n;
+    return KKD_OK;
+}
