@@ -20,36 +20,39 @@ struct Microfacet {
     __device__ Microfacet(int t, float au, float av, bool sv) : type(t), alphaU(au), alphaV(av), sampleVisible(sv), expU(0.f), expV(0.f) {
         if (type == KKD_DISTR_PHONG) {
             sampleVisible = false;
-            expU = fmaxf(2.0f / (alphaU * alphaU) - 2.0f, 0.0f);
-            expV = fmaxf(2.0f / (alphaV * alphaV) - 2.0f, 0.0f);
+            expU = fmaxf(fdiv(2.0f, alphaU * alphaU) - 2.0f, 0.0f);
+            expV = fmaxf(fdiv(2.0f, alphaV * alphaV) - 2.0f, 0.0f);
         }
     }
     __device__ bool isotropic() const { return alphaU == alphaV; }
     __device__ float projectRoughness(f3 v) const {
-        float invSinTheta2 = 1.f / (1.f - v.z * v.z);
-        if (isotropic() || invSinTheta2 <= 0.f) return alphaU;
+        if (isotropic()) return alphaU;
+        float invSinTheta2 = frcp(1.f - v.z * v.z);
+        if (invSinTheta2 <= 0.f) return alphaU;
         float cosPhi2 = v.x * v.x * invSinTheta2, sinPhi2 = v.y * v.y * invSinTheta2;
-        return sqrtf(cosPhi2 * alphaU * alphaU + sinPhi2 * alphaV * alphaV);
+        return fsqrt(cosPhi2 * alphaU * alphaU + sinPhi2 * alphaV * alphaV);
     }
     __device__ float interpolatePhongExponent(f3 v) const {
-        float invSinTheta2 = 1.f / (1.f - v.z * v.z);
-        if (isotropic() || invSinTheta2 <= 0.f) return expU;
+        if (isotropic()) return expU;
+        float invSinTheta2 = frcp(1.f - v.z * v.z);
+        if (invSinTheta2 <= 0.f) return expU;
         float cosPhi2 = v.x * v.x * invSinTheta2, sinPhi2 = v.y * v.y * invSinTheta2;
         return expU * cosPhi2 + expV * sinPhi2;
     }
     __device__ float eval(f3 m) const {
         if (m.z <= 0.f) return 0.0f;
         float cosTheta2 = m.z * m.z;
-        float beckmannExponent = ((m.x * m.x) / (alphaU * alphaU) + (m.y * m.y) / (alphaV * alphaV)) / cosTheta2;
+        float beckmannExponent = (isotropic() ? fdiv(m.x * m.x + m.y * m.y, alphaU * alphaU)
+                                               : fdiv(m.x * m.x, alphaU * alphaU) + fdiv(m.y * m.y, alphaV * alphaV)) * frcp(cosTheta2);
         float result;
         if (type == KKD_DISTR_BECKMANN) {
-            result = expf(-beckmannExponent) / (kPi * alphaU * alphaV * cosTheta2 * cosTheta2);
+            result = fdiv(expf(-beckmannExponent), kPi * alphaU * alphaV * cosTheta2 * cosTheta2);
         } else if (type == KKD_DISTR_GGX) {
             float root = (1.0f + beckmannExponent) * cosTheta2;
-            result = 1.0f / (kPi * alphaU * alphaV * root * root);
+            result = frcp(kPi * alphaU * alphaV * root * root);
         } else {
             float exponent = interpolatePhongExponent(m);
-            result = sqrtf((expU + 2.f) * (expV + 2.f)) * kInvTwoPi * powf(m.z, exponent);
+            result = fsqrt((expU + 2.f) * (expV + 2.f)) * kInvTwoPi * powf(m.z, exponent);
         }
         if (result * m.z < 1e-20f) result = 0.f;
         return result;
@@ -57,25 +60,25 @@ struct Microfacet {
     __device__ float smithG1(f3 v, f3 m) const {
         if (dot(v, m) * v.z <= 0.f) return 0.0f;
         float temp = 1.f - v.z * v.z;
-        float tanTheta = temp <= 0.f ? 0.f : fabsf(sqrtf(temp) / v.z);
+        float tanTheta = temp <= 0.f ? 0.f : fabsf(fdiv(fsqrt(temp), v.z));
         if (tanTheta == 0.0f) return 1.0f;
         float alpha = projectRoughness(v);
         if (type == KKD_DISTR_GGX) {
             float root = alpha * tanTheta;
-            return 2.0f / (1.0f + sqrtf(1.0f + root * root));
+            return fdiv(2.0f, 1.0f + fsqrt(1.0f + root * root));
         }
-        float a = 1.0f / (alpha * tanTheta);
+        float a = frcp(alpha * tanTheta);
         if (a >= 1.6f) return 1.0f;
         float aSqr = a * a;
-        return (3.535f * a + 2.181f * aSqr) / (1.0f + 2.276f * a + 2.577f * aSqr);
+        return fdiv(3.535f * a + 2.181f * aSqr, 1.0f + 2.276f * a + 2.577f * aSqr);
     }
     __device__ float G(f3 wi, f3 wo, f3 m) const { return smithG1(wi, m) * smithG1(wo, m); }
     __device__ float pdfAll(f3 m) const { return eval(m) * m.z; }
-    __device__ float pdfVisible(f3 wi, f3 m) const { return smithG1(wi, m) * fabsf(dot(wi, m)) * eval(m) / fabsf(wi.z); }
+    __device__ float pdfVisible(f3 wi, f3 m) const { return fdiv(smithG1(wi, m) * fabsf(dot(wi, m)) * eval(m), fabsf(wi.z)); }
     __device__ float pdf(f3 wi, f3 m) const { return sampleVisible ? pdfVisible(wi, m) : pdfAll(m); }
 
     __device__ void sampleFirstQuadrant(float u1, float &phi, float &exponent) const {
-        phi = atanf(sqrtf((expU + 2.0f) / (expV + 2.0f)) * tanf(kPi * u1 * 0.5f));
+        phi = atanf(fsqrt(fdiv(expU + 2.0f, expV + 2.0f)) * tanf(kPi * u1 * 0.5f));
         float c = cosf(phi), s = sinf(phi);
         exponent = expU * c * c + expV * s * s;
     }
@@ -86,20 +89,20 @@ struct Microfacet {
                 sincosf((2.0f * kPi) * sample.y, &sinPhiM, &cosPhiM);
                 alphaSqr = alphaU * alphaU;
             } else {
-                float phiM = atanf(alphaV / alphaU * tanf(kPi + 2.f * kPi * sample.y)) + kPi * floorf(2.f * sample.y + 0.5f);
+                float phiM = atanf(fdiv(alphaV, alphaU) * tanf(kPi + 2.f * kPi * sample.y)) + kPi * floorf(2.f * sample.y + 0.5f);
                 sincosf(phiM, &sinPhiM, &cosPhiM);
-                float cosSc = cosPhiM / alphaU, sinSc = sinPhiM / alphaV;
-                alphaSqr = 1.0f / (cosSc * cosSc + sinSc * sinSc);
+                float cosSc = fdiv(cosPhiM, alphaU), sinSc = fdiv(sinPhiM, alphaV);
+                alphaSqr = frcp(cosSc * cosSc + sinSc * sinSc);
             }
             if (type == KKD_DISTR_BECKMANN) {
                 float tanThetaMSqr = alphaSqr * -logf(1.0f - sample.x);
-                cosThetaM = 1.0f / sqrtf(1.0f + tanThetaMSqr);
-                pdf = (1.0f - sample.x) / (kPi * alphaU * alphaV * cosThetaM * cosThetaM * cosThetaM);
+                cosThetaM = frsq(1.0f + tanThetaMSqr);
+                pdf = fdiv(1.0f - sample.x, kPi * alphaU * alphaV * cosThetaM * cosThetaM * cosThetaM);
             } else {
-                float tanThetaMSqr = alphaSqr * sample.x / (1.0f - sample.x);
-                cosThetaM = 1.0f / sqrtf(1.0f + tanThetaMSqr);
-                float temp = 1.f + tanThetaMSqr / alphaSqr;
-                pdf = kInvPi / (alphaU * alphaV * cosThetaM * cosThetaM * cosThetaM * temp * temp);
+                float tanThetaMSqr = fdiv(alphaSqr * sample.x, 1.0f - sample.x);
+                cosThetaM = frsq(1.0f + tanThetaMSqr);
+                float temp = 1.f + fdiv(tanThetaMSqr, alphaSqr);
+                pdf = fdiv(kInvPi, alphaU * alphaV * cosThetaM * cosThetaM * cosThetaM * temp * temp);
             }
         } else {
             float phiM, exponent;
@@ -109,11 +112,11 @@ struct Microfacet {
             else if (sample.y < 0.75f) { sampleFirstQuadrant(4.f * (sample.y - 0.5f), phiM, exponent); phiM += kPi; }
             else { sampleFirstQuadrant(4.f * (1.f - sample.y), phiM, exponent); phiM = 2.f * kPi - phiM; }
             sincosf(phiM, &sinPhiM, &cosPhiM);
-            cosThetaM = powf(sample.x, 1.0f / (exponent + 2.0f));
-            pdf = sqrtf((expU + 2.0f) * (expV + 2.0f)) * kInvTwoPi * powf(cosThetaM, exponent + 1.0f);
+            cosThetaM = powf(sample.x, frcp(exponent + 2.0f));
+            pdf = fsqrt((expU + 2.0f) * (expV + 2.0f)) * kInvTwoPi * powf(cosThetaM, exponent + 1.0f);
         }
         if (pdf < 1e-20f) pdf = 0.f;
-        float sinThetaM = sqrtf(fmaxf(0.f, 1.f - cosThetaM * cosThetaM));
+        float sinThetaM = fsqrt(fmaxf(0.f, 1.f - cosThetaM * cosThetaM));
         return f3(sinThetaM * cosPhiM, sinThetaM * sinPhiM, cosThetaM);
     }
     __device__ f2 sampleVisible11(float thetaI, f2 sample) const {
@@ -121,16 +124,16 @@ struct Microfacet {
         f2 slope;
         if (type == KKD_DISTR_BECKMANN) {
             if (thetaI < 1e-4f) {
-                float r = sqrtf(-logf(1.0f - sample.x)), s, c;
+                float r = fsqrt(-logf(1.0f - sample.x)), s, c;
                 sincosf(2.f * kPi * sample.y, &s, &c);
                 return f2{ r * c, r * s };
             }
-            float tanThetaI = tanf(thetaI), cotThetaI = 1.f / tanThetaI;
+            float tanThetaI = tanf(thetaI), cotThetaI = frcp(tanThetaI);
             float a = -1.f, c = erfApprox(cotThetaI);
             float sample_x = fmaxf(sample.x, 1e-6f);
             float fit = 1.f + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
             float b = c - (1.f + c) * powf(1.f - sample_x, fit);
-            float normalization = 1.f / (1.f + c + SQRT_PI_INV * tanThetaI * expf(-cotThetaI * cotThetaI));
+            float normalization = frcp(1.f + c + SQRT_PI_INV * tanThetaI * expf(-cotThetaI * cotThetaI));
             int it = 0;
             while (++it < 10) {
                 if (!(b >= a && b <= c)) b = 0.5f * (a + c);
@@ -139,32 +142,32 @@ struct Microfacet {
                 float derivative = normalization * (1.f - invErf * tanThetaI);
                 if (fabsf(value) < 1e-5f) break;
                 if (value > 0.f) c = b; else a = b;
-                b -= value / derivative;
+                b -= fdiv(value, derivative);
             }
             slope.x = erfinvApprox(b);
             slope.y = erfinvApprox(2.0f * fmaxf(sample.y, 1e-6f) - 1.0f);
         } else {
             if (thetaI < 1e-4f) {
-                float r = safeSqrt(sample.x / (1.f - sample.x)), s, c;
+                float r = safeSqrt(fdiv(sample.x, 1.f - sample.x)), s, c;
                 sincosf(2.f * kPi * sample.y, &s, &c);
                 return f2{ r * c, r * s };
             }
             float tanThetaI = tanf(thetaI);
-            float a = 1.f / tanThetaI;
-            float G1 = 2.0f / (1.0f + safeSqrt(1.0f + 1.0f / (a * a)));
-            float A = 2.0f * sample.x / G1 - 1.0f;
+            float a = frcp(tanThetaI);
+            float G1 = fdiv(2.0f, 1.0f + safeSqrt(1.0f + frcp(a * a)));
+            float A = fdiv(2.0f * sample.x, G1) - 1.0f;
             if (fabsf(A) == 1.f) A -= signum(A) * kEpsilon;
-            float tmp = 1.0f / (A * A - 1.0f);
+            float tmp = frcp(A * A - 1.0f);
             float B = tanThetaI;
             float D = safeSqrt(B * B * tmp * tmp - (A * A - B * B) * tmp);
             float slope_x_1 = B * tmp - D, slope_x_2 = B * tmp + D;
-            slope.x = (A < 0.0f || slope_x_2 > 1.0f / tanThetaI) ? slope_x_1 : slope_x_2;
+            slope.x = (A < 0.0f || slope_x_2 > a) ? slope_x_1 : slope_x_2;
             float S;
             if (sample.y > 0.5f) { S = 1.0f; sample.y = 2.0f * (sample.y - 0.5f); }
             else { S = -1.0f; sample.y = 2.0f * (0.5f - sample.y); }
-            float z = (sample.y * (sample.y * (sample.y * (-0.365728915865723f) + 0.790235037209296f) - 0.424965825137544f) + 0.000152998850436920f) /
-                      (sample.y * (sample.y * (sample.y * (sample.y * 0.169507819808272f - 0.397203533833404f) - 0.232500544458471f) + 1.0f) - 0.539825872510702f);
-            slope.y = S * z * sqrtf(1.0f + slope.x * slope.x);
+            float z = fdiv(sample.y * (sample.y * (sample.y * (-0.365728915865723f) + 0.790235037209296f) - 0.424965825137544f) + 0.000152998850436920f,
+                           sample.y * (sample.y * (sample.y * (sample.y * 0.169507819808272f - 0.397203533833404f) - 0.232500544458471f) + 1.0f) - 0.539825872510702f);
+            slope.y = S * z * fsqrt(1.0f + slope.x * slope.x);
         }
         return slope;
     }
@@ -177,7 +180,7 @@ struct Microfacet {
         f2 slope = sampleVisible11(theta, sample);
         slope = f2{ cosPhi * slope.x - sinPhi * slope.y, sinPhi * slope.x + cosPhi * slope.y };
         slope.x *= alphaU; slope.y *= alphaV;
-        float normalization = 1.0f / sqrtf(slope.x * slope.x + slope.y * slope.y + 1.0f);
+        float normalization = frsq(slope.x * slope.x + slope.y * slope.y + 1.0f);
         return f3(-slope.x * normalization, -slope.y * normalization, normalization);
     }
     __device__ f3 sample(f3 wi, f2 s, float &pdfOut) const {
@@ -191,7 +194,7 @@ __device__ __forceinline__ f3 reflectLocal(f3 wi, f3 m) { return 2.f * dot(wi, m
 
 /* rtrans.h:183-191: Catmull-Rom lookup in cosTheta^(1/4), clamped to [0,1] */
 __device__ __forceinline__ float roughTransEval(const float *tab, float cosTheta) {
-    float x = sqrtf(sqrtf(fabsf(cosTheta)));   /* cosTheta^(1/4), rtrans.h:187 */
+    float x = fsqrt(fsqrt(fabsf(cosTheta)));   /* cosTheta^(1/4), rtrans.h:187 */
     if (!(x >= 0.f && x <= 1.f)) return 0.f;
     float t = x * 99.f;
     int k = max(0, min((int)t, 98));
@@ -205,7 +208,7 @@ __device__ __forceinline__ float roughTransEval(const float *tab, float cosTheta
 }
 __device__ __forceinline__ float plasticProbSpecular(const DMaterial &m, const float *tab, float cosThetaI) {
     float p = 1.f - roughTransEval(tab, cosThetaI);
-    return (p * m.specSamplingWeight) / (p * m.specSamplingWeight + (1.f - p) * (1.f - m.specSamplingWeight));
+    return fdiv(p * m.specSamplingWeight, p * m.specSamplingWeight + (1.f - p) * (1.f - m.specSamplingWeight));
 }
 
 /* eval / pdf of a non-twosided material (wi.z sign already resolved by the caller) */
@@ -221,7 +224,7 @@ __device__ __forceinline__ f3 bsdfEvalBase(const DMaterial &m, const float *rtTa
             float D = distr.eval(H);
             if (D == 0.f) return f3(0.f);
             f3 F = fresnelConductorExact(dot(wi, H), ld3(m.condEta), ld3(m.condK)) * ld3(m.specRefl);
-            float model = D * distr.G(wi, wo, H) / (4.0f * wi.z);
+            float model = fdiv(D * distr.G(wi, wo, H), 4.0f * wi.z);
             return F * model;
         }
         case KKD_BSDF_ROUGHPLASTIC: {
@@ -229,11 +232,11 @@ __device__ __forceinline__ f3 bsdfEvalBase(const DMaterial &m, const float *rtTa
             const float *tab = rtTables + m.tableOffset;
             Microfacet distr(m.distr, m.alphaU, m.alphaU, m.sampleVisible != 0);
             f3 H = normalize(wo + wi);
-            float value = fresnelDielectricExt(dot(wi, H), m.eta) * distr.eval(H) * distr.G(wi, wo, H) / (4.0f * wi.z);
+            float value = fdiv(fresnelDielectricExt(dot(wi, H), m.eta) * distr.eval(H) * distr.G(wi, wo, H), 4.0f * wi.z);
             f3 result = ld3(m.specRefl) * value;
             f3 diff = ld3(m.refl);
             float T12 = roughTransEval(tab, wi.z), T21 = roughTransEval(tab, wo.z);
-            if (m.nonlinear) diff = diff / (f3(1.0f) - diff * m.fdr); else diff = diff / (1.f - m.fdr);
+            if (m.nonlinear) diff = diff / (f3(1.0f) - diff * m.fdr); else diff = diff * frcp(1.f - m.fdr);
             result += diff * (kInvPi * wo.z * T12 * T21 * m.invEta2);
             return result;
         }
@@ -249,8 +252,8 @@ __device__ __forceinline__ float bsdfPdfBase(const DMaterial &m, const float *rt
             if (wi.z < 0.f || wo.z < 0.f) return 0.f;
             f3 H = normalize(wo + wi);
             Microfacet distr(m.distr, m.alphaU, m.alphaV, m.sampleVisible != 0);
-            if (distr.sampleVisible) return distr.eval(H) * distr.smithG1(wi, H) / (4.0f * wi.z);
-            return distr.pdf(wi, H) / (4.f * fabsf(dot(wo, H)));
+            if (distr.sampleVisible) return fdiv(distr.eval(H) * distr.smithG1(wi, H), 4.0f * wi.z);
+            return fdiv(distr.pdf(wi, H), 4.f * fabsf(dot(wo, H)));
         }
         case KKD_BSDF_ROUGHPLASTIC: {
             if (wi.z <= 0.f || wo.z <= 0.f) return 0.f;
@@ -258,7 +261,7 @@ __device__ __forceinline__ float bsdfPdfBase(const DMaterial &m, const float *rt
             Microfacet distr(m.distr, m.alphaU, m.alphaU, m.sampleVisible != 0);
             f3 H = normalize(wo + wi);
             float probSpecular = plasticProbSpecular(m, tab, wi.z);
-            float result = distr.pdf(wi, H) * (1.0f / (4.0f * dot(wo, H))) * probSpecular;
+            float result = distr.pdf(wi, H) * frcp(4.0f * dot(wo, H)) * probSpecular;
             result += (1.f - probSpecular) * (kInvPi * wo.z);
             return result;
         }
@@ -286,8 +289,8 @@ __device__ __forceinline__ f3 bsdfSampleBase(const DMaterial &m, const float *rt
             f3 F = fresnelConductorExact(dot(wi, mm), ld3(m.condEta), ld3(m.condK)) * ld3(m.specRefl);
             float weight;
             if (distr.sampleVisible) weight = distr.smithG1(wo, mm);
-            else weight = distr.eval(mm) * distr.G(wi, wo, mm) * dot(wi, mm) / (pdfOut * wi.z);
-            pdfOut /= 4.0f * dot(wo, mm);
+            else weight = fdiv(distr.eval(mm) * distr.G(wi, wo, mm) * dot(wi, mm), pdfOut * wi.z);
+            pdfOut = fdiv(pdfOut, 4.0f * dot(wo, mm));
             return F * weight;
         }
         case KKD_BSDF_ROUGHPLASTIC: {
@@ -296,8 +299,8 @@ __device__ __forceinline__ f3 bsdfSampleBase(const DMaterial &m, const float *rt
             Microfacet distr(m.distr, m.alphaU, m.alphaU, m.sampleVisible != 0);
             float probSpecular = plasticProbSpecular(m, tab, wi.z);
             bool choseSpecular = true;
-            if (s.y < probSpecular) s.y /= probSpecular;
-            else { s.y = (s.y - probSpecular) / (1.f - probSpecular); choseSpecular = false; }
+            if (s.y < probSpecular) s.y = fdiv(s.y, probSpecular);
+            else { s.y = fdiv(s.y - probSpecular, 1.f - probSpecular); choseSpecular = false; }
             if (choseSpecular) {
                 float dummy;
                 f3 mm = distr.sampleVisible ? distr.sampleVisibleNormal(wi, s) : distr.sampleAll(s, dummy);
@@ -322,7 +325,7 @@ __device__ __forceinline__ f3 bsdfSampleBase(const DMaterial &m, const float *rt
                 return ld3(m.specRefl);
             }
             sampledType = EDeltaTransmission;
-            float factor = cosThetaT < 0.f ? 1.f / m.eta : m.eta;
+            float factor = cosThetaT < 0.f ? frcp(m.eta) : m.eta;
             wo = f3(-factor * wi.x, -factor * wi.y, cosThetaT);
             pdfOut = 1.f - F;
             return ld3(m.specTrans) * (factor * factor);

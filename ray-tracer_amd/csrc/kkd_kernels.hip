@@ -257,7 +257,8 @@ __global__ void __launch_bounds__(256, 4) kShade(DScene sc, BatchParams bp, Wave
     }
     const uint32_t btype = sc.materials[its.material].typeFlags;
     const f3 refN = (btype & (ETransmission | EBackSide)) ? f3(0.f) : its.sh.n;   /* DirectSamplingRecord(its) */
-    const float cB = nB / (float)(nB + nL), cL = nL / (float)(nB + nL);            /* :163-166 */
+    const float cB = fdiv((float)nB, (float)(nB + nL)), cL = fdiv((float)nL, (float)(nB + nL));            /* :163-166 */
+    const float invNL = frcp((float)nL);
     /* sibling integrator on the same kernels: MIDirectIntegrator::Li (integrators/direct/direct.cpp:176-311) draws the
      * emitter samples before the BSDF samples, applies the geometric-normal tests only with 'strictNormals', samples
      * emitters only for smooth BSDFs and weights with the power heuristic */
@@ -300,8 +301,8 @@ __global__ void __launch_bounds__(256, 4) kShade(DScene sc, BatchParams bp, Wave
                     const bool onSurface = sc.emitters[dRec.emitter].type != KKD_EMITTER_POINT;
                     const float bsdfPdf = onSurface ? pdfBsdf(sc, its.material, its.wi, woLocal) : 0.f;
                     const float pa = cL * dRec.pdf, pb = cB * bsdfPdf;
-                    const float weight = stock ? (pa * pa) / (pa * pa + pb * pb) : pa / (pb + pa);   /* direct.cpp:241-243, 313-316 */
-                    const f3 contrib = value * bsdfVal * (weight / (float)nL);
+                    const float weight = stock ? fdiv(pa * pa, pa * pa + pb * pb) : fdiv(pa, pb + pa);   /* direct.cpp:241-243, 313-316 */
+                    const f3 contrib = value * bsdfVal * (weight * invNL);
                     rec = make_float4(contrib.x, contrib.y, contrib.z, 0.f);
                     r.ox = its.p.x; r.oy = its.p.y; r.oz = its.p.z; r.mint = kEpsilon;   /* scene.cpp:840-841 */
                     r.dx = dRec.d.x; r.dy = dRec.d.y; r.dz = dRec.d.z; r.maxt = dRec.dist * (1.f - kShadowEpsilon);
@@ -399,7 +400,8 @@ __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveB
         sx = (float)s.X + jit.x; sy = (float)s.Y + jit.y;
         const float4 acc = wb.accum[i];
         f3 L(acc.x, acc.y, acc.z);
-        const float cB = nB / (float)(nB + nL), cL = nL / (float)(nB + nL);
+        const float cB = fdiv((float)nB, (float)(nB + nL)), cL = fdiv((float)nL, (float)(nB + nL));
+        const float invNB = frcp((float)nB);
         for (uint32_t b = 0; b < nB; ++b) {                        /* kk/direct.cpp:105-123 + :167-171 */
             const float4 rec = wb.brec0[(size_t)b * bp.stride + i];
             if (rec.w == 0.f || (bp.debug & 2u)) continue;
@@ -428,8 +430,8 @@ __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveB
             const float bsdfPdf = fabsf(rec.w);
             const float lightPdf = rec.w > 0.f ? pdfEmitterDirect(sc, dRec) : 0.f;
             const float pa = cB * bsdfPdf, pb = cL * lightPdf;
-            const float weight = bp.integrator == KKD_INTEGRATOR_DIRECT ? (pa * pa) / (pa * pa + pb * pb) : pa / (pa + pb);   /* direct.cpp:303-305 */
-            L += value * f3(rec.x, rec.y, rec.z) * (weight / (float)nB);
+            const float weight = bp.integrator == KKD_INTEGRATOR_DIRECT ? fdiv(pa * pa, pa * pa + pb * pb) : fdiv(pa, pa + pb);   /* direct.cpp:303-305 */
+            L += value * f3(rec.x, rec.y, rec.z) * (weight * invNB);
         }
         for (uint32_t l = 0; l < nL; ++l) {
             const float4 rec = wb.lrec[(size_t)l * bp.stride + i];

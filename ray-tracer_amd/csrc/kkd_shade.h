@@ -33,7 +33,7 @@ __device__ __forceinline__ DRay sensorRay(const DSensor &s, float px, float py) 
     float cx = m[0] * x + m[1] * y + m[3], cy = m[4] * x + m[5] * y + m[7], cz = m[8] * x + m[9] * y + m[11], cw = m[12] * x + m[13] * y + m[15];
     f3 nearP = (cw == 1.0f) ? f3(cx, cy, cz) : f3(cx, cy, cz) / cw;
     f3 d = normalize(nearP);
-    const float invZ = 1.0f / d.z;
+    const float invZ = frcp(d.z);
     const float *w = s.toWorld;
     DRay r;
     r.ox = w[3]; r.oy = w[7]; r.oz = w[11];
@@ -80,7 +80,7 @@ __device__ __forceinline__ void fillIntersection(const DScene &sc, f3 rayD, cons
             const float det = du1 * dv2 - dv1 * du2;
             if (len == 0.f) dpdu = f3(0.f);
             else if (det == 0.f) { f3 tv; coordinateSystem(cross(side1, side2) / len, dpdu, tv); }
-            else dpdu = (side1 * dv2 - side2 * dv1) * (1.0f / det);
+            else dpdu = (side1 * dv2 - side2 * dv1) * frcp(det);
         }
         its.sh.s = normalize(dpdu - n * dot(n, dpdu));
         its.sh.t = cross(n, its.sh.s);
@@ -104,7 +104,7 @@ __device__ __forceinline__ uint32_t cdfSampleReuse(const float *cdf, uint32_t n,
     const uint32_t index = cdfSample(cdf, n, v);
     const float c0 = cdf[index], c1 = cdf[index + 1];
     pdf = c1 - c0;
-    v = (v - c0) / (c1 - c0);
+    v = fdiv(v - c0, c1 - c0);
     return index;
 }
 /* envmap.cpp:653-658 */
@@ -116,7 +116,7 @@ __device__ __forceinline__ uint32_t envSampleReuse(const float *cdf, uint32_t si
     }
     const uint32_t index = min(lo > 0 ? lo - 1 : 0u, size - 1);
     const float c0 = cdf[index], c1 = cdf[index + 1];
-    sample = (sample - c0) / (c1 - c0);
+    sample = fdiv(sample - c0, c1 - c0);
     return index;
 }
 
@@ -155,7 +155,7 @@ __device__ __forceinline__ float envPdfDirection(const DEnvMap &e, f3 d) {
     envBilinearRows(e, uu * e.w - 0.5f, vv * e.h - 0.5f, a, b, yPos);
     const float sinTheta = safeSqrt(1.f - d.y * d.y);
     return (luminance(a) * e.rowWeights[min(max(yPos, 0), e.h - 1)] + luminance(b) * e.rowWeights[min(max(yPos + 1, 0), e.h - 1)])
-           * e.normalization / fmaxf(fabsf(sinTheta), kEpsilon);
+           * e.normalization * frcp(fmaxf(fabsf(sinTheta), kEpsilon));
 }
 /* envmap.cpp:567-600 */
 __device__ __forceinline__ void envSampleDirection(const DEnvMap &e, f2 sample, f3 &d, f3 &value, float &pdf) {
@@ -170,7 +170,7 @@ __device__ __forceinline__ void envSampleDirection(const DEnvMap &e, f2 sample, 
     sincosf(e.pixelSizeX * (px + 0.5f), &sinPhi, &cosPhi);
     sincosf(e.pixelSizeY * (py + 0.5f), &sinTheta, &cosTheta);
     d = f3(sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta);
-    pdf /= fmaxf(fabsf(sinTheta), kEpsilon);
+    pdf *= frcp(fmaxf(fabsf(sinTheta), kEpsilon));
 }
 
 /* area.cpp:104-109 */
@@ -204,10 +204,10 @@ __device__ __forceinline__ f3 sampleEmitterDirectUnoccluded(const DScene &sc, Di
         dRec.pdf = e.invArea;
         dRec.d = dRec.p - dRec.ref;
         const float distSquared = dot(dRec.d, dRec.d);
-        dRec.dist = sqrtf(distSquared);
+        dRec.dist = fsqrt(distSquared);
         dRec.d = dRec.d / dRec.dist;
         const float dp = fabsf(dot(dRec.d, dRec.n));
-        dRec.pdf *= dp != 0.f ? (distSquared / dp) : 0.0f;
+        dRec.pdf *= dp != 0.f ? fdiv(distSquared, dp) : 0.0f;
         dRec.measure = 0;
         if (dot(dRec.d, dRec.refN) >= 0.f && dot(dRec.d, dRec.n) < 0.f && dRec.pdf != 0.f)
             value = f3(e.radiance[0], e.radiance[1], e.radiance[2]) / dRec.pdf;
@@ -216,7 +216,7 @@ __device__ __forceinline__ f3 sampleEmitterDirectUnoccluded(const DScene &sc, Di
         dRec.p = f3(e.position[0], e.position[1], e.position[2]); dRec.pdf = 1.0f; dRec.measure = 1;
         dRec.d = dRec.p - dRec.ref;
         dRec.dist = length(dRec.d);
-        const float invDist = 1.0f / dRec.dist;
+        const float invDist = frcp(dRec.dist);
         dRec.d = dRec.d * invDist;
         dRec.n = f3(0.f);
         value = f3(e.radiance[0], e.radiance[1], e.radiance[2]) * (invDist * invDist);
@@ -248,7 +248,7 @@ __device__ __forceinline__ float pdfEmitterDirect(const DScene &sc, const Direct
     float pdf = 0.f;
     if (e.type == KKD_EMITTER_AREA) {
         if (dot(dRec.d, dRec.refN) >= 0.f && dot(dRec.d, dRec.n) < 0.f)
-            pdf = e.invArea * (dRec.dist * dRec.dist) / fabsf(dot(dRec.d, dRec.n));
+            pdf = fdiv(e.invArea * (dRec.dist * dRec.dist), fabsf(dot(dRec.d, dRec.n)));
     } else if (e.type == KKD_EMITTER_POINT) {
         pdf = dRec.measure == 1 ? 1.0f : 0.0f;
     } else {

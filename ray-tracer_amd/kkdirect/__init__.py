@@ -31,7 +31,7 @@ def load_library(path=None):
     """dlopen libkkdirect.so and bind every entry point the header declares."""
     global _lib
     if _lib is None or path is not None:
-        p = path or LIB_PATH
+        p = path or os.environ.get("KKD_LIB") or LIB_PATH   # $KKD_LIB: A/B runs of experimental builds
         if not os.path.exists(p):
             raise FileNotFoundError("libkkdirect.so not built: run __graft_entry__.build() (looked at %s)" % p)
         _lib = abi.bind(C.CDLL(p))
