@@ -163,6 +163,11 @@ typedef struct kkd_scene_desc {
                                         src/librender/skdtree.cpp:77-104, 294-300) instead of the watertight test: hit ids then
                                         equal ShapeKDTree's except for equal-distance ties; not watertight on shared edges */
 
+#define KKD_FLAG_ONE_LANE 4u         /* renders normally keep two batches of camera samples in flight on two HIP streams (the
+                                        issue-bound kernels of one fill the slots the latency-bound traversal of the other leaves
+                                        idle); with this flag batches run one after the other on the context's stream, so that
+                                        kkd_stats.stage_seconds are the kernels' exclusive durations (measurement runs) */
+
 typedef struct kkd_config {
     int32_t  device;           /* HIP device ordinal                                           */
     uint32_t flags;            /* KKD_FLAG_*                                                   */

@@ -36,10 +36,13 @@ struct DevBuf {
 
 } /* namespace */
 
+static constexpr int kMaxLanes = 4;
+
 struct kkd_ctx {
     int device = 0;
     kkd_config cfg{};
     hipStream_t stream = nullptr;
+    hipStream_t laneStreams[kMaxLanes - 1] = {};    /* further batch lanes of a render (created on first use) */
     std::string err;
     std::atomic<int> cancel{0};
     bool haveScene = false;
@@ -114,6 +117,7 @@ void kkd_request_cancel(kkd_ctx *ctx) { if (ctx) ctx->cancel.store(1); }
 void kkd_destroy(kkd_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    for (hipStream_t s : ctx->laneStreams) if (s) hipStreamSynchronize(s);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     DevBuf *all[] = { &ctx->nodes, &ctx->wideNodes, &ctx->tris, &ctx->projTris, &ctx->positions, &ctx->normals, &ctx->texcoords, &ctx->indices, &ctx->shapes, &ctx->materials,
                       &ctx->emitters, &ctx->emitterCdf, &ctx->areaCdf, &ctx->rtTables, &ctx->envTexels, &ctx->envCdfRows, &ctx->envCdfCols,
@@ -121,6 +125,7 @@ void kkd_destroy(kkd_ctx *ctx) {
                       &ctx->occluded, &ctx->lrec, &ctx->film, &ctx->counters, &ctx->apiRays, &ctx->apiHits };
     for (DevBuf *b : all) b->release();
     for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
+    for (hipStream_t s : ctx->laneStreams) if (s) hipStreamDestroy(s);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -345,39 +350,64 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     const uint32_t g = std::min(64u, pow2ceil(rp->spp)), chunks = (rp->spp + g - 1) / g;
     uint32_t gShift = 0; while ((1u << gShift) < g) ++gShift;
     const uint64_t total = (uint64_t)nTilesMine * bs * bs * chunks * g;
-    uint64_t batch = ctx->cfg.max_samples_in_flight ? ctx->cfg.max_samples_in_flight : (1ull << 23);
+    uint64_t batch = ctx->cfg.max_samples_in_flight ? ctx->cfg.max_samples_in_flight : (1ull << 24);
     batch = std::max<uint64_t>(256, (batch + 255) / 256 * 256);
     batch = std::min<uint64_t>(batch, 1ull << 28);
     batch = std::min<uint64_t>(batch, std::max<uint64_t>(256, (total + 255) / 256 * 256));
+    static const int envLanesDefault = [] { const char *e = getenv("KKD_STREAMS"); return e ? atoi(e) : 2; }();
+    const int envLanes = (ctx->cfg.flags & KKD_FLAG_ONE_LANE) ? 1 : envLanesDefault;
+    if (!ctx->cfg.max_samples_in_flight && envLanes >= 2 && total >= (1ull << 21)) {
+        /* library default: an even number of equal batches, so both batch lanes (below) work to the end */
+        uint64_t nb = (total + batch - 1) / batch;
+        nb = std::max<uint64_t>(2, nb + (nb & 1));
+        batch = ((total + nb - 1) / nb + 255) / 256 * 256;
+    }
     const uint32_t nB = rp->bsdf_samples, nL = rp->light_samples;
     const size_t S = (size_t)batch;
 
+    const uint64_t nBatches = (total + batch - 1) / batch;
+    /* Batch lanes: consecutive batches alternate between two streams with their own wavefront buffers, so the
+     * issue-bound kernels of one batch (sample generation, shading, splat) fill the issue slots the latency-bound
+     * traversal kernels of the other leave idle.  Batches only meet in the film and the counters (atomic adds).
+     * $KKD_STREAMS=1 switches back to one lane. */
+    const int nLanes = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min(envLanes, kMaxLanes), nBatches));
     hipError_t e = hipSuccess;
+    for (int l = 1; l < nLanes && e == hipSuccess; ++l)
+        if (!ctx->laneStreams[l - 1]) e = hipStreamCreateWithFlags(&ctx->laneStreams[l - 1], hipStreamNonBlocking);
+    if (e != hipSuccess) return fail(ctx, KKD_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     auto need = [&](DevBuf &b, size_t bytes) { if (e == hipSuccess) e = b.ensure(bytes); };
-    need(ctx->hits, S * sizeof(DHit)); need(ctx->accum, S * 16); need(ctx->refN, S * 16);
-    need(ctx->bsdfRays, S * nB * sizeof(DRay)); need(ctx->bsdfHits, S * nB * sizeof(DHit)); need(ctx->brec0, S * nB * 16);
+    auto needL = [&](DevBuf &b, size_t bytes) { if (e == hipSuccess) e = b.ensure(((bytes + 255) / 256 * 256) * nLanes); };   /* one copy per lane */
+    auto laneP = [&](DevBuf &b, size_t bytes, int lane) { return (char *)b.p + ((bytes + 255) / 256 * 256) * lane; };
+    needL(ctx->hits, S * sizeof(DHit)); needL(ctx->accum, S * 16); needL(ctx->refN, S * 16);
+    needL(ctx->bsdfRays, S * nB * sizeof(DRay)); needL(ctx->bsdfHits, S * nB * sizeof(DHit)); needL(ctx->brec0, S * nB * 16);
     /* continuation buffer of the two-launch traversal: a quarter of the largest ray launch may be parked */
     /* $KKD_ITER_CAP_CLOSEST / _ANY pin the budgets (0 = one launch, no rounds); else they adapt, see below */
     static const int envCapClosest = [] { const char *e = getenv("KKD_ITER_CAP_CLOSEST"); return e ? atoi(e) : -1; }();
     static const int envCapAny = [] { const char *e = getenv("KKD_ITER_CAP_ANY"); return e ? atoi(e) : -1; }();
     const int capClosest = envCapClosest >= 0 ? envCapClosest : ctx->capClosest, capAny = envCapAny >= 0 ? envCapAny : ctx->capAny;
     const uint64_t contCap = std::min<uint64_t>(((uint64_t)S * std::max(nB, nL) / 2 / kContShards + 128) * kContShards, 0x7fffffffull);   /* two halves of n/4 records */
-    need(ctx->contRecs, contCap * sizeof(ContRec)); need(ctx->contStacks, contCap * 16 * sizeof(uint32_t)); need(ctx->contCount, 4 * kContShards * 32 * sizeof(uint32_t));   /* closest: 2 ping-pong counter arrays, any: 2 */
-    need(ctx->shadowRays, S * nL * sizeof(DRay)); need(ctx->occluded, S * nL * 4); need(ctx->lrec, S * nL * 16);
+    needL(ctx->contRecs, contCap * sizeof(ContRec)); needL(ctx->contStacks, contCap * 16 * sizeof(uint32_t)); needL(ctx->contCount, 4 * kContShards * 32 * sizeof(uint32_t));   /* closest: 2 ping-pong counter arrays, any: 2 */
+    needL(ctx->shadowRays, S * nL * sizeof(DRay)); needL(ctx->occluded, S * nL * 4); needL(ctx->lrec, S * nL * 16);
     need(ctx->counters, kCounterShards * sizeof(DeviceCounters));
     if (!devFilm) need(ctx->film, (size_t)W * H * 5 * sizeof(float));
     if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? KKD_ERR_NOMEM : KKD_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
     float *film = devFilm ? devFilm : (float *)ctx->film.p;
 
-    TraceContinuation cont; cont.recs = (ContRec *)ctx->contRecs.p; cont.stacks = (uint4 *)ctx->contStacks.p; cont.count = (uint32_t *)ctx->contCount.p;
-    cont.perShard = (uint32_t)(contCap / kContShards); cont.iterCap = 0;
+    TraceContinuation contL[kMaxLanes]; WaveBuffers wbL[kMaxLanes];
+    for (int l = 0; l < nLanes; ++l) {
+        TraceContinuation &cont = contL[l]; WaveBuffers &wb = wbL[l];
+        cont.recs = (ContRec *)laneP(ctx->contRecs, contCap * sizeof(ContRec), l); cont.stacks = (uint4 *)laneP(ctx->contStacks, contCap * 16 * sizeof(uint32_t), l);
+        cont.count = (uint32_t *)laneP(ctx->contCount, 4 * kContShards * 32 * sizeof(uint32_t), l);
+        cont.perShard = (uint32_t)(contCap / kContShards); cont.iterCap = 0;
+        wb.hits = (DHit *)laneP(ctx->hits, S * sizeof(DHit), l); wb.accum = (float4 *)laneP(ctx->accum, S * 16, l); wb.refN = (float4 *)laneP(ctx->refN, S * 16, l);
+        wb.bsdfRays = (DRay *)laneP(ctx->bsdfRays, S * nB * sizeof(DRay), l); wb.bsdfHits = (DHit *)laneP(ctx->bsdfHits, S * nB * sizeof(DHit), l);
+        wb.brec0 = (float4 *)laneP(ctx->brec0, S * nB * 16, l);
+        wb.shadowRays = (DRay *)laneP(ctx->shadowRays, S * nL * sizeof(DRay), l); wb.occluded = (uint32_t *)laneP(ctx->occluded, S * nL * 4, l);
+        wb.lrec = (float4 *)laneP(ctx->lrec, S * nL * 16, l);
+    }
     static const int capLater = [] { const char *e = getenv("KKD_ITER_CAP_LATER"); return e ? atoi(e) : 8; }();
     static const int rounds = [] { const char *e = getenv("KKD_TRACE_ROUNDS"); return e ? atoi(e) : 2; }();
-    cont.iterCapLater = capLater; cont.rounds = rounds;
-    WaveBuffers wb;
-    wb.hits = (DHit *)ctx->hits.p; wb.accum = (float4 *)ctx->accum.p; wb.refN = (float4 *)ctx->refN.p;
-    wb.bsdfRays = (DRay *)ctx->bsdfRays.p; wb.bsdfHits = (DHit *)ctx->bsdfHits.p; wb.brec0 = (float4 *)ctx->brec0.p;
-    wb.shadowRays = (DRay *)ctx->shadowRays.p; wb.occluded = (uint32_t *)ctx->occluded.p; wb.lrec = (float4 *)ctx->lrec.p;
+    for (int l = 0; l < nLanes; ++l) { contL[l].iterCapLater = capLater; contL[l].rounds = rounds; }
     DeviceCounters *ctr = (DeviceCounters *)ctx->counters.p;
 
     BatchParams bp;
@@ -393,22 +423,31 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     bp.tileIndex = tileIndex; bp.tileCount = tileCount; bp.nTilesMine = nTilesMine; bp.W = W; bp.H = H;
     { const char *dbg = getenv("KKD_DEBUG"); bp.debug = dbg ? (uint32_t)atoi(dbg) : 0u; }
 
-    const uint64_t nBatches = (total + batch - 1) / batch;
     const bool count = (ctx->cfg.flags & KKD_FLAG_COUNT_TRAVERSAL) != 0;
-    /* one event between consecutive kernels of a batch: 6 per batch, on the stream the kernels run on */
+    /* one event between consecutive kernels of a batch: 6 per batch, on the stream the kernels run on; events 0 / 1 bracket
+     * the render on the context's stream, 2 forks and 3... join the other lanes */
     const bool timeStages = stats != nullptr && nBatches <= 8192;
-    const size_t nEvents = 2 + (timeStages ? (size_t)nBatches * 6 : 0);
+    const size_t evBase = 3 + kMaxLanes;
+    const size_t nEvents = evBase + (timeStages ? (size_t)nBatches * 6 : 0);
     while (ctx->events.size() < nEvents) { hipEvent_t ev; KKD_HIP(ctx, hipEventCreate(&ev)); ctx->events.push_back(ev); }
 
-    hipStream_t st = ctx->stream;
-    KKD_HIP(ctx, hipMemsetAsync(film, 0, (size_t)W * H * 5 * sizeof(float), st));
-    KKD_HIP(ctx, hipMemsetAsync(ctr, 0, kCounterShards * sizeof(DeviceCounters), st));
-    KKD_HIP(ctx, hipEventRecord(ctx->events[0], st));
-    size_t ev = 2;
+    const hipStream_t st0 = ctx->stream, laneStream[kMaxLanes] = { ctx->stream, ctx->laneStreams[0], ctx->laneStreams[1], ctx->laneStreams[2] };
+    KKD_HIP(ctx, hipMemsetAsync(film, 0, (size_t)W * H * 5 * sizeof(float), st0));
+    KKD_HIP(ctx, hipMemsetAsync(ctr, 0, kCounterShards * sizeof(DeviceCounters), st0));
+    KKD_HIP(ctx, hipEventRecord(ctx->events[0], st0));
+    if (nLanes > 1) {   /* the other lanes start after the film and the counters are cleared */
+        KKD_HIP(ctx, hipEventRecord(ctx->events[2], st0));
+        for (int l = 1; l < nLanes; ++l) KKD_HIP(ctx, hipStreamWaitEvent(laneStream[l], ctx->events[2], 0));
+    }
+    size_t ev = evBase;
     uint64_t launches[5] = { 0, 0, 0, 0, 0 };
     bool cancelled = false;
-    for (uint64_t w0 = 0; w0 < total; w0 += batch) {
+    uint64_t batchIndex = 0;
+    for (uint64_t w0 = 0; w0 < total; w0 += batch, ++batchIndex) {
         if (ctx->cancel.load()) { cancelled = true; break; }
+        const int lane = (int)(batchIndex % (uint64_t)nLanes);
+        const hipStream_t st = laneStream[lane];
+        const WaveBuffers &wb = wbL[lane]; const TraceContinuation &cont = contL[lane];
         bp.w0 = w0; bp.count = (uint32_t)std::min<uint64_t>(batch, total - w0);
         {   /* w0 is a multiple of 256 and g divides 256: lane group = w0 / g + (i >> gShift) */
             const uint64_t group0 = w0 >> gShift, slot0 = group0 / chunks, pixPerTile = (uint64_t)bs * bs;
@@ -437,10 +476,14 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         if (timeStages) hipEventRecord(ctx->events[ev++], st);
     }
     KKD_HIP(ctx, hipGetLastError());
-    KKD_HIP(ctx, hipEventRecord(ctx->events[1], st));
+    for (int l = 1; l < nLanes; ++l) {   /* join: the context's stream continues after the other lanes have drained */
+        KKD_HIP(ctx, hipEventRecord(ctx->events[2 + l], laneStream[l]));
+        KKD_HIP(ctx, hipStreamWaitEvent(st0, ctx->events[2 + l], 0));
+    }
+    KKD_HIP(ctx, hipEventRecord(ctx->events[1], st0));
     std::vector<DeviceCounters> shards(kCounterShards);
-    KKD_HIP(ctx, hipMemcpyAsync(shards.data(), ctr, kCounterShards * sizeof(DeviceCounters), hipMemcpyDeviceToHost, st));
-    KKD_HIP(ctx, hipStreamSynchronize(st));
+    KKD_HIP(ctx, hipMemcpyAsync(shards.data(), ctr, kCounterShards * sizeof(DeviceCounters), hipMemcpyDeviceToHost, st0));
+    KKD_HIP(ctx, hipStreamSynchronize(st0));
     const DeviceCounters c = sumShards(shards);
     {
         /* Budget control over the whole render: too many parked rays and the second round repeats their set-up for
@@ -461,7 +504,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         KKD_HIP(ctx, hipEventElapsedTime(&ms, ctx->events[0], ctx->events[1]));
         fillCounterStats(stats, c, count);
         stats->seconds = ms * 1e-3;
-        if (timeStages) for (size_t k = 2; k + 5 < ev; k += 6)
+        if (timeStages) for (size_t k = evBase; k + 5 < ev; k += 6)
             for (int sIdx = 0; sIdx < 5; ++sIdx) { float t = 0.f; if (hipEventElapsedTime(&t, ctx->events[k + sIdx], ctx->events[k + sIdx + 1]) == hipSuccess) stats->stage_seconds[sIdx] += t * 1e-3; }
         for (int sIdx = 0; sIdx < 5; ++sIdx) stats->stage_launches[sIdx] = launches[sIdx];
         stats->seconds_trace = stats->stage_seconds[KKD_STAGE_PRIMARY] + stats->stage_seconds[KKD_STAGE_BSDF] + stats->stage_seconds[KKD_STAGE_SHADOW];

@@ -45,9 +45,9 @@ def device_count():
 class Context:
     """One kkd_ctx: one GPU, one uploaded scene."""
 
-    def __init__(self, device=0, seed=1, max_samples_in_flight=0, count_traversal=False, projection_test=False):
+    def __init__(self, device=0, seed=1, max_samples_in_flight=0, count_traversal=False, projection_test=False, one_lane=False):
         self.lib = load_library()
-        cfg = abi.Config(device, (abi.FLAG_COUNT_TRAVERSAL if count_traversal else 0) | (abi.FLAG_PROJECTION_TEST if projection_test else 0),
+        cfg = abi.Config(device, (abi.FLAG_COUNT_TRAVERSAL if count_traversal else 0) | (abi.FLAG_PROJECTION_TEST if projection_test else 0) | (abi.FLAG_ONE_LANE if one_lane else 0),
                          seed, max_samples_in_flight)
         self.h = self.lib.kkd_create(C.byref(cfg))
         if not self.h:

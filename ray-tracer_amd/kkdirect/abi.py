@@ -16,6 +16,7 @@ RFILTER_GAUSSIAN, RFILTER_BOX, RFILTER_TENT, RFILTER_MITCHELL, RFILTER_CATMULLRO
 SHAPE_HAS_NORMALS, SHAPE_HAS_TEXCOORDS = 1, 2
 FLAG_COUNT_TRAVERSAL = 1
 FLAG_PROJECTION_TEST = 2
+FLAG_ONE_LANE = 4
 PIXEL_LUMINANCE, PIXEL_LUMINANCE_ALPHA, PIXEL_RGB, PIXEL_RGBA, PIXEL_XYZ, PIXEL_XYZA = range(6)
 PIXEL_CHANNELS = {PIXEL_LUMINANCE: 1, PIXEL_LUMINANCE_ALPHA: 2, PIXEL_RGB: 3, PIXEL_RGBA: 4, PIXEL_XYZ: 3, PIXEL_XYZA: 4}
 PIXEL_FORMATS = {"luminance": PIXEL_LUMINANCE, "luminancealpha": PIXEL_LUMINANCE_ALPHA, "rgb": PIXEL_RGB, "rgba": PIXEL_RGBA,

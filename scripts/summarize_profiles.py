@@ -23,6 +23,8 @@ def counting(name):   # counting variants (COUNT template argument true) are not
 
 shutil.copy(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0], os.path.join(dst, "%s_bench_c2_kernel_stats.csv" % tag))
 shutil.copy(os.path.join(src, "bench_under_trace.json"), os.path.join(dst, "%s_bench_c2_under_rocprof.json" % tag))
+shutil.copy(glob.glob(os.path.join(src, "trace1", "*", "*kernel_stats.csv"))[0], os.path.join(dst, "%s_bench_c2_one_lane_kernel_stats.csv" % tag))
+shutil.copy(os.path.join(src, "bench_under_trace1.json"), os.path.join(dst, "%s_bench_c2_one_lane_under_rocprof.json" % tag))
 
 def pmc(dirname):
     acc = defaultdict(lambda: defaultdict(list))
@@ -42,7 +44,7 @@ for st in ("primary", "shade", "bsdf", "shadow", "resolve"):
     out[st] = {"launches_sampled": len(fs), "FETCH_SIZE_KiB_per_launch": round(f_avg, 1), "WRITE_SIZE_KiB_per_launch": round(w_avg, 1),
                "hbm_bytes_per_launch": round((2 * f_avg + w_avg) * 1024), "l2_hit_rate": round(hit / max(1.0, hit + miss), 4)}
 json.dump({"c2": {k: v["hbm_bytes_per_launch"] for k, v in out.items()}, "_detail_c2": out,
-           "_note": "per launch of one 8M-sample batch (bench.py --spp 32, same batch size as the headline run); (2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes, scripts/profile_r1.sh"},
+           "_note": "per launch of one 16.6M-sample batch (bench.py --spp 32 gives the batch size of the headline run), one lane; (2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes, scripts/profile_r1.sh"},
           open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 print(open(os.path.join(dst, "%s_bench_c2_kernel_stats.csv" % tag)).read()[:1500])

@@ -74,3 +74,24 @@ def test_deep_stacks_spill_and_are_not_parked(gpu):
         film, st = ctx.render(4)                                   # and through the round-based render path
         ref, _ = o.render(4, seed=1)
     assert helpers.rel_mse(helpers.develop(film), helpers.develop(ref)) < 1e-4
+
+
+@pytest.mark.gpu
+def test_two_batch_lanes_equal_one_lane():
+    """Renders keep two batches in flight on two streams (kkd_api.hip, 'batch lanes'); KKD_FLAG_ONE_LANE runs the same batches
+    one after the other.  Same samples, same rays, same film up to the order of the float atomics -- for the library's own
+    batch split (an even number of equal batches) and for a caller-chosen odd one."""
+    import kkdirect
+    from kkdirect import scenes
+    sc = scenes.sponza_class(512, 288, target_tris=20_000)
+    for in_flight in (0, 700_000):
+        films, stats = [], []
+        for one in (True, False):
+            with kkdirect.Context(device=0, seed=3, max_samples_in_flight=in_flight, one_lane=one).upload(sc) as ctx:
+                f, s = ctx.render(32)            # 4.7 M samples: 2 batches by default, 7 with 700 k in flight
+                films.append(f); stats.append(s)
+        assert stats[0].samples == stats[1].samples == 512 * 288 * 32
+        assert stats[0].rays_closest == stats[1].rays_closest and stats[0].rays_shadow == stats[1].rays_shadow
+        assert stats[1].stage_launches[0] >= 2          # more than one batch, so the second lane was used
+        np.testing.assert_allclose(films[0], films[1], rtol=2e-4, atol=1e-4)
+        assert np.isfinite(films[1]).all()
