@@ -260,7 +260,8 @@ bool flattenScene(const kkd_scene_desc *sd, HostScene &hs, std::string &err, int
     if (!sd->positions || !sd->indices || !sd->n_verts || !sd->n_tris) KKD_FAIL(KKD_ERR_INVALID, "scene has no geometry");
     if (!sd->n_shapes || !sd->shapes || !sd->n_materials || !sd->materials) KKD_FAIL(KKD_ERR_INVALID, "scene has no shapes or materials");
     if (sd->n_emitters && !sd->emitters) KKD_FAIL(KKD_ERR_INVALID, "emitters pointer is NULL");
-    if (sd->n_verts > 0xFFFFFFFFull) KKD_FAIL(KKD_ERR_INVALID, "more than 2^32 vertices");
+    /* device code indexes the vertex and index tables with 32-bit element offsets (3 * i) */
+    if (sd->n_verts > 0xFFFFFFFFull / 3 || sd->n_tris > 0xFFFFFFFFull / 3) KKD_FAIL(KKD_ERR_INVALID, "more than 2^32 / 3 vertices or triangles");
     hs.nVerts = sd->n_verts; hs.nTris = sd->n_tris;
     hs.hasNormals = sd->normals != nullptr; hs.hasTexcoords = sd->texcoords != nullptr;
     for (uint64_t i = 0; i < 3 * sd->n_tris; ++i)

@@ -24,7 +24,9 @@ struct Its {
 
 struct DirectRec { f3 ref, refN, p, n, d; float dist, pdf; int measure /* 0 solid angle, 1 discrete */; int emitter; };
 
-__device__ __forceinline__ f3 ldv(const float *base, uint32_t i) { const float *p = base + 3 * (size_t)i; return f3(p[0], p[1], p[2]); }
+/* element offsets are computed in 32 bits (3u * i is a shift-add; a 64-bit index multiply is a quarter-rate v_mad_u64_u32):
+ * vertex, index and triangle tables stay below 2^32 elements, which kkd_scene_upload checks */
+__device__ __forceinline__ f3 ldv(const float *base, uint32_t i) { const float *p = base + 3u * i; return f3(p[0], p[1], p[2]); }
 
 /* perspective.cpp:271-298 */
 __device__ __forceinline__ DRay sensorRay(const DSensor &s, float px, float py) {
@@ -48,7 +50,7 @@ __device__ __forceinline__ DRay sensorRay(const DSensor &s, float px, float py) 
  * need p / shading normal). */
 template <bool FULL>
 __device__ __forceinline__ void fillIntersection(const DScene &sc, f3 rayD, const DHit &hit, Its &its) {
-    const float4 *tp = reinterpret_cast<const float4 *>(sc.tris) + (size_t)hit.id * 3;
+    const float4 *tp = reinterpret_cast<const float4 *>(sc.tris) + 3u * hit.id;
     const float4 a = tp[0], b = tp[1], c = tp[2];
     const uint32_t prim = __float_as_uint(a.w), sh = __float_as_uint(b.w);
     const DShape shape = sc.shapes[sh];
@@ -62,7 +64,7 @@ __device__ __forceinline__ void fillIntersection(const DScene &sc, f3 rayD, cons
     if (len != 0.f) faceNormal = faceNormal / len;
     uint32_t i0 = 0, i1 = 0, i2 = 0;
     if (shape.flags & (KKD_SHAPE_HAS_NORMALS | KKD_SHAPE_HAS_TEXCOORDS)) {
-        const uint32_t *ip = sc.indices + 3 * (size_t)prim;
+        const uint32_t *ip = sc.indices + 3u * prim;
         i0 = ip[0]; i1 = ip[1]; i2 = ip[2];
     }
     f3 n;
@@ -75,7 +77,7 @@ __device__ __forceinline__ void fillIntersection(const DScene &sc, f3 rayD, cons
     if (FULL) {
         f3 dpdu = side1;
         if (shape.flags & KKD_SHAPE_HAS_TEXCOORDS) {   /* trimesh.cpp:687-747 */
-            const float *t0 = sc.texcoords + 2 * (size_t)i0, *t1 = sc.texcoords + 2 * (size_t)i1, *t2 = sc.texcoords + 2 * (size_t)i2;
+            const float *t0 = sc.texcoords + 2u * i0, *t1 = sc.texcoords + 2u * i1, *t2 = sc.texcoords + 2u * i2;
             const float du1 = t1[0] - t0[0], dv1 = t1[1] - t0[1], du2 = t2[0] - t0[0], dv2 = t2[1] - t0[1];
             const float det = du1 * dv2 - dv1 * du2;
             if (len == 0.f) dpdu = f3(0.f);
@@ -191,7 +193,7 @@ __device__ __forceinline__ f3 sampleEmitterDirectUnoccluded(const DScene &sc, Di
         float dummy;
         const uint32_t local = cdfSampleReuse(sc.areaCdf + e.cdfOffset, e.nPrims, sample.y, dummy);
         const uint32_t prim = e.firstPrim + local;
-        const uint32_t *ip = sc.indices + 3 * (size_t)prim;
+        const uint32_t *ip = sc.indices + 3u * prim;
         const uint32_t i0 = ip[0], i1 = ip[1], i2 = ip[2];
         const f3 p0 = ldv(sc.positions, i0), p1 = ldv(sc.positions, i1), p2 = ldv(sc.positions, i2);
         const f2 bary = squareToUniformTriangle(sample);

@@ -200,7 +200,7 @@ struct Walk {
                 if (atLeaf) {
                     const uint32_t slot = cur & kLeafStartMask;
                     if (COUNT) ++nTris;
-                    const float4 *tp = tris4 + (size_t)slot * 3;
+                    const float4 *tp = tris4 + 3u * slot;   /* 32-bit shift-add, not a quarter-rate 64-bit multiply */
                     const float4 a = tp[0], b = tp[1], c = tp[2];
                     float t, u, v;
                     bool done = false;
@@ -295,7 +295,7 @@ __device__ __forceinline__ DHit traversePacket(const WideNode *__restrict__ wnod
         } else {
             const uint32_t start = cur & kLeafStartMask, cnt = ((cur >> 28) & 7u) + 1u;
             for (uint32_t i = 0; i < cnt; ++i) {
-                const float4 *tp = tris4 + (size_t)(start + i) * 3;
+                const float4 *tp = tris4 + 3u * (start + i);
                 const float4 a = tp[0], b = tp[1], c = tp[2];
                 float t, u, v;
                 if (PROJ ? projIntersect(ox, oy, oz, ray.dx, ray.dy, ray.dz, a, b, c, tmin, tmax, t, u, v)
