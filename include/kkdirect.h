@@ -190,12 +190,19 @@ typedef struct kkd_render_params {
     /* which Li: KKD_INTEGRATOR_KK = the path of this library, DirectIntegrator::Li (src/integrators/kk/direct.cpp:50-178);
      * KKD_INTEGRATOR_DIRECT = its sibling on the same kernels, MIDirectIntegrator::Li of the stock 'direct' plugin
      * (src/integrators/direct/direct.cpp:147-311): emitter samples first, power heuristic, 'strictNormals'; there
-     * light_samples is 'emitterSamples' and one of the two counts may be 0. */
+     * light_samples is 'emitterSamples' and one of the two counts may be 0;
+     * KKD_INTEGRATOR_PATH = the next sibling, MIPathTracer::Li of the stock 'path' plugin (src/integrators/path/path.cpp:
+     * 119-294): one emitter sample and one BSDF sample per vertex, power heuristic, 'maxDepth' / 'rrDepth' /
+     * 'strictNormals' / 'hideEmitters' of MonteCarloIntegrator (src/librender/integrator.cpp:190-233); bsdf_samples and
+     * light_samples are ignored. */
     uint32_t integrator;
-    int32_t  strict_normals;   /* 'strictNormals' of the direct plugin (direct.cpp:103); ignored by KKD_INTEGRATOR_KK */
+    int32_t  strict_normals;   /* 'strictNormals' of the direct / path plugins (direct.cpp:103); ignored by KKD_INTEGRATOR_KK */
+    int32_t  max_depth;        /* path: 'maxDepth' (-1 = unbounded, 1 = emitted radiance only, 2 = direct illumination ...); 0 is invalid */
+    int32_t  rr_depth;         /* path: 'rrDepth', first depth at which Russian roulette is played (> 0; Mitsuba's default 5) */
 } kkd_render_params;
 #define KKD_INTEGRATOR_KK     0u
 #define KKD_INTEGRATOR_DIRECT 1u
+#define KKD_INTEGRATOR_PATH   2u
 
 /* ray classes / kernel stages of one render (indices of the arrays in kkd_stats) */
 #define KKD_RAYS_PRIMARY 0   /* sensor rays, closest hit   (kernel kPrimary)                      */

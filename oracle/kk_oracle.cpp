@@ -54,9 +54,10 @@ int ora_intersect_record(ora_ctx *c, const float *r, float *out) {
 }
 
 int ora_render(ora_ctx *c, const kkd_render_params *p, uint64_t seed, int threads, float *film, kkd_stats *stats) {
-    if (!p->spp || p->bsdf_samples + p->light_samples == 0) return KKD_ERR_UNSUPPORTED;
+    if (p->integrator == KKD_INTEGRATOR_PATH) { if (!p->spp || p->max_depth == 0 || p->rr_depth <= 0) return KKD_ERR_INVALID; }
+    else if (!p->spp || p->bsdf_samples + p->light_samples == 0) return KKD_ERR_UNSUPPORTED;
     if (p->integrator == KKD_INTEGRATOR_KK && (!p->bsdf_samples || !p->light_samples)) return KKD_ERR_UNSUPPORTED;
-    RenderParams rp{ p->spp, p->bsdf_samples, p->light_samples, p->hide_emitters != 0, p->block_size, p->tile_index, p->tile_count, p->sample_first, seed, p->integrator, p->strict_normals != 0 };
+    RenderParams rp{ p->spp, p->bsdf_samples, p->light_samples, p->hide_emitters != 0, p->block_size, p->tile_index, p->tile_count, p->sample_first, seed, p->integrator, p->strict_normals != 0, p->max_depth, p->rr_depth };
     Stats st;
     auto t0 = std::chrono::steady_clock::now();
     c->scene.render(rp, film, &st, threads);
@@ -71,7 +72,7 @@ int ora_render(ora_ctx *c, const kkd_render_params *p, uint64_t seed, int thread
 
 /* Radiance of single camera samples, no film: pix = n x (x, y, sampleIndex); out = n x (r,g,b,alpha,sx,sy). */
 int ora_li_samples(ora_ctx *c, const kkd_render_params *p, uint64_t seed, const uint32_t *pix, uint64_t n, float *out) {
-    RenderParams rp{ p->spp, p->bsdf_samples, p->light_samples, p->hide_emitters != 0, p->block_size, 0, 1, 0, seed, p->integrator, p->strict_normals != 0 };
+    RenderParams rp{ p->spp, p->bsdf_samples, p->light_samples, p->hide_emitters != 0, p->block_size, 0, 1, 0, seed, p->integrator, p->strict_normals != 0, p->max_depth, p->rr_depth };
     const int W = c->scene.sensor.cropW;
     for (uint64_t i = 0; i < n; ++i) {
         uint32_t X = pix[3 * i], Y = pix[3 * i + 1], s = pix[3 * i + 2];

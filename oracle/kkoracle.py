@@ -110,9 +110,9 @@ class Oracle:
         return rays
 
     def render(self, spp, bsdf_samples=1, light_samples=1, hide_emitters=False, seed=1, threads=None, block_size=0,
-               tile_index=0, tile_count=1, sample_first=0, integrator=0, strict_normals=False):
+               tile_index=0, tile_count=1, sample_first=0, integrator=0, strict_normals=False, max_depth=-1, rr_depth=5):
         p = abi.RenderParams(spp, bsdf_samples, light_samples, int(hide_emitters), block_size, tile_index, tile_count, sample_first,
-                             integrator, int(strict_normals))
+                             integrator, int(strict_normals), max_depth, rr_depth)
         film = np.zeros((self.height, self.width, 5), np.float32)
         st = abi.Stats()
         rc = lib().ora_render(self.h, C.byref(p), seed, threads or os.cpu_count() or 1, _fp(film), C.byref(st))

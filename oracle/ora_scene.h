@@ -343,7 +343,7 @@ struct Sensor {
 };
 
 struct RenderParams { uint32_t spp, nB, nL; bool hideEmitters; uint32_t blockSize, tileIndex, tileCount, sampleFirst; uint64_t seed;
-                      uint32_t integrator = 0; bool strictNormals = false; };
+                      uint32_t integrator = 0; bool strictNormals = false; int maxDepth = -1, rrDepth = 5; };
 struct Stats { std::atomic<uint64_t> samples{0}, raysClosest{0}, raysShadow{0}, nodes{0}, tris{0}; };
 
 class Scene {
@@ -392,6 +392,7 @@ public:
     /* ---- integrator ---- */
     V3 Li(const Ray &ray, SampleStream &rng, const RenderParams &rp, Float &alpha, Stats *st) const;
     V3 LiDirectPlugin(const Ray &ray, const Intersection &its, int bsdf, uint32_t btype, V3 refN, SampleStream &rng, const RenderParams &rp, Stats *st) const;
+    V3 LiPath(const Ray &ray, SampleStream &rng, const RenderParams &rp, Float &alpha, Stats *st) const;
     void render(const RenderParams &rp, float *film, Stats *st, int nThreads) const;
 };
 
@@ -511,6 +512,7 @@ inline Float Scene::pdfEmitterDirect(const DirectRec &dRec) const {
 
 /* integrators/kk/direct.cpp:50-178 */
 inline V3 Scene::Li(const Ray &ray, SampleStream &rng, const RenderParams &rp, Float &alpha, Stats *st) const {
+    if (rp.integrator == KKD_INTEGRATOR_PATH) return LiPath(ray, rng, rp, alpha, st);
     struct SV { V3 value, bsdfValue; Float pdf, otherPdf; };
     V3 L(0.f);
     Hit hit;
@@ -639,6 +641,96 @@ inline V3 Scene::LiDirectPlugin(const Ray &ray, const Intersection &its, int bsd
         L += value * bsdfVal * weight;
     }
     return L;
+}
+
+/* MIPathTracer::Li, integrators/path/path.cpp:119-294 (parameters: MonteCarloIntegrator, librender/integrator.cpp:190-233).
+ * Sample dimensions (counter-based stream instead of the sequential sampler): the vertex at depth d uses dimensions
+ * 2 + 6 (d - 1) ... : emitter sample (2), BSDF sample (2), Russian roulette (1), one unused -- for d = 1 these are the
+ * dimensions of the direct plugin with one emitter and one BSDF sample, so maxDepth = 2 reproduces it sample by sample. */
+inline V3 Scene::LiPath(const Ray &r, SampleStream &rng, const RenderParams &rp, Float &alpha, Stats *st) const {
+    auto miWeight = [](Float a, Float b) { a *= a; b *= b; return a / (a + b); };        /* :296-300 */
+    Ray ray = r;
+    V3 Li(0.f), throughput(1.f);
+    Float eta = 1.0f;
+    bool scattered = false;
+    int depth = 1;                                                                       /* RadianceQueryRecord::newQuery */
+    bool emitted = true;                                                                 /* rRec.type & EEmittedRadiance */
+    Hit hit; Intersection its;
+    bool valid = rayIntersect(ray, hit, st);                                             /* :129 */
+    if (valid) fillIntersection(ray, hit, its);
+    else if (filmHasAlpha) alpha = 0;                                                    /* integrator.cpp: rRec.alpha */
+    ray.mint = kEpsilon;
+    while (depth <= rp.maxDepth || rp.maxDepth < 0) {                                    /* :135 */
+        if (!valid) {                                                                    /* :136-143 */
+            if (emitted && (!rp.hideEmitters || scattered) && envEmitter >= 0) Li += throughput * env.evalEnvironment(ray.d);
+            break;
+        }
+        const ShapeRec &shape = shapes[its.shape];
+        const int bsdf = shape.material;
+        if (shape.emitter >= 0 && emitted && (!rp.hideEmitters || scattered))            /* :148-150 */
+            Li += throughput * emitterEvalArea(emitters[shape.emitter], its, -ray.d);
+        if ((depth >= rp.maxDepth && rp.maxDepth > 0) || (rp.strictNormals && dot(ray.d, its.geoFrame.n) * its.wi.z >= 0)) break;   /* :156-165 */
+        rng.dim = 2u + 6u * (uint32_t)(depth - 1);
+        const uint32_t btype = bsdfs.getType(bsdf);
+        DirectRec dRec; dRec.ref = its.p; dRec.refN = (btype & (ETransmission | EBackSide)) ? V3(0.f) : its.shFrame.n;
+        {                                                                                /* :172-200 */
+            V2 u = rng.next2D();
+            if (btype & ESmooth) {
+                V3 value = sampleEmitterDirect(dRec, u, st);
+                if (!isZero(value)) {
+                    const EmitterRec &e = emitters[dRec.emitter];
+                    V3 woLocal = its.toLocal(dRec.d);
+                    const V3 bsdfVal = bsdfs.eval(bsdf, its.wi, woLocal);
+                    if (!isZero(bsdfVal) && (!rp.strictNormals || dot(its.geoFrame.n, dRec.d) * woLocal.z > 0)) {
+                        Float bsdfPdf = (e.type != KKD_EMITTER_POINT) ? bsdfs.pdf(bsdf, its.wi, woLocal) : 0;
+                        Li += throughput * value * bsdfVal * miWeight(dRec.pdf, bsdfPdf);
+                    }
+                }
+            }
+        }
+        V2 u = rng.next2D();                                                             /* :206-219 */
+        V3 woLocal; Float bsdfPdf; uint32_t sampledType;
+        V3 bsdfWeight = bsdfs.sample(bsdf, its.wi, u, woLocal, bsdfPdf, sampledType);
+        if (isZero(bsdfWeight)) break;
+        scattered = true;                                                                /* no ENull component among the BSDFs of this path */
+        const V3 wo = its.toWorld(woLocal);
+        if (rp.strictNormals && dot(its.geoFrame.n, wo) * woLocal.z <= 0) break;
+        /* bRec.eta: relative index along the sampled direction (dielectric.cpp:300-308), 1 for reflection */
+        Float bRecEta = 1.0f;
+        if (sampledType == EDeltaTransmission) { const Float e = bsdfs.mats[bsdf].eta; bRecEta = its.wi.z > 0 ? e : 1 / e; }
+        bool hitEmitter = false;
+        V3 value(0.f);
+        ray = Ray(its.p, wo, kEpsilon, std::numeric_limits<Float>::infinity());          /* :225 */
+        valid = rayIntersect(ray, hit, st);
+        if (valid) {                                                                     /* :226-232 */
+            fillIntersection(ray, hit, its);
+            const ShapeRec &bs = shapes[its.shape];
+            if (bs.emitter >= 0) {
+                value = emitterEvalArea(emitters[bs.emitter], its, -ray.d);
+                dRec.p = its.p; dRec.n = its.shFrame.n; dRec.d = ray.d; dRec.dist = its.t; dRec.measure = 0; dRec.emitter = bs.emitter;
+                hitEmitter = true;
+            }
+        } else {                                                                         /* :233-248 */
+            if (envEmitter < 0) break;
+            value = env.evalEnvironment(ray.d);
+            if (!envFillDirectRec(dRec, ray)) break;
+            hitEmitter = true;
+        }
+        throughput = throughput * bsdfWeight;                                            /* :252-253 */
+        eta *= bRecEta;
+        if (hitEmitter) {                                                                /* :257-264 */
+            const Float lumPdf = !(sampledType & EDelta) ? pdfEmitterDirect(dRec) : 0;
+            Li += throughput * value * miWeight(bsdfPdf, lumPdf);
+        }
+        if (!valid) break;                                                               /* :272-274 */
+        emitted = false;
+        if (depth++ >= rp.rrDepth) {                                                     /* :276-286 */
+            Float q = std::min(maxComp(throughput) * eta * eta, (Float)0.95f);
+            if (rng.next1D() >= q) break;
+            throughput = throughput / q;
+        }
+    }
+    return Li;
 }
 
 /* integrator.cpp:140-188 over all tiles of imageproc.cpp:28-78; the film receives every block as

@@ -52,7 +52,7 @@ struct kkd_ctx {
     DevBuf nodes, wideNodes, tris, projTris, positions, normals, texcoords, indices, shapes, materials, emitters, emitterCdf, areaCdf, rtTables,
            envTexels, envCdfRows, envCdfCols, envRowWeights;
     /* work buffers */
-    DevBuf contRecs, contStacks, contCount;
+    DevBuf contRecs, contStacks, contCount, pathAlive;
     /* first-round step budgets of the round-based traversal; adapted from the share of rays the last batch parked */
     int capClosest = 28, capAny = 20;
     DevBuf hits, accum, refN, bsdfRays, bsdfHits, brec0, shadowRays, occluded, lrec, film, counters, apiRays, apiHits;
@@ -330,12 +330,16 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     if (!rp) return fail(ctx, KKD_ERR_INVALID, "render params are NULL");
     if (rp->spp == 0) return fail(ctx, KKD_ERR_INVALID, "spp must be positive");
     /* kk/direct.cpp:165-166 divides by both counts: zero is not a meaningful configuration */
-    if (rp->integrator > KKD_INTEGRATOR_DIRECT) return fail(ctx, KKD_ERR_INVALID, "unknown integrator");
+    if (rp->integrator > KKD_INTEGRATOR_PATH) return fail(ctx, KKD_ERR_INVALID, "unknown integrator");
+    const bool pathMode = rp->integrator == KKD_INTEGRATOR_PATH;
+    /* MonteCarloIntegrator (librender/integrator.cpp:190-233): maxDepth = -1 or > 0, rrDepth > 0 */
+    if (pathMode && (rp->max_depth == 0 || rp->max_depth < -1)) return fail(ctx, KKD_ERR_INVALID, "maxDepth must be -1 (unbounded) or positive");
+    if (pathMode && rp->rr_depth <= 0) return fail(ctx, KKD_ERR_INVALID, "rrDepth must be greater than zero");
     if (rp->integrator == KKD_INTEGRATOR_KK && (rp->bsdf_samples == 0 || rp->light_samples == 0))
         return fail(ctx, KKD_ERR_UNSUPPORTED, "bsdfSamples and lightSamples must be >= 1");
     /* the stock plugin only asserts emitterSamples + bsdfSamples > 0 (integrators/direct/direct.cpp:107) */
-    if (rp->bsdf_samples + rp->light_samples == 0) return fail(ctx, KKD_ERR_INVALID, "emitterSamples + bsdfSamples must be > 0");
-    if (rp->bsdf_samples > 64 || rp->light_samples > 64) return fail(ctx, KKD_ERR_UNSUPPORTED, "bsdfSamples / lightSamples above 64");
+    if (!pathMode && rp->bsdf_samples + rp->light_samples == 0) return fail(ctx, KKD_ERR_INVALID, "emitterSamples + bsdfSamples must be > 0");
+    if (!pathMode && (rp->bsdf_samples > 64 || rp->light_samples > 64)) return fail(ctx, KKD_ERR_UNSUPPORTED, "bsdfSamples / lightSamples above 64");
     const uint32_t bs = rp->block_size ? rp->block_size : 32;                    /* scene.cpp:24 */
     if (bs < 2 || bs > 128) return fail(ctx, KKD_ERR_INVALID, "block size must be in [2, 128]");   /* mitsuba.cpp:142 */
     if ((int)bs < ctx->ds.filter.border) return fail(ctx, KKD_ERR_INVALID, "block size must be >= the filter border");   /* renderproc.cpp:173-174 */
@@ -362,7 +366,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         nb = std::max<uint64_t>(2, nb + (nb & 1));
         batch = ((total + nb - 1) / nb + 255) / 256 * 256;
     }
-    const uint32_t nB = rp->bsdf_samples, nL = rp->light_samples;
+    const uint32_t nB = pathMode ? 1u : rp->bsdf_samples, nL = pathMode ? 1u : rp->light_samples;   /* path.cpp: one of each per vertex */
     const size_t S = (size_t)batch;
 
     const uint64_t nBatches = (total + batch - 1) / batch;
@@ -389,6 +393,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     needL(ctx->contRecs, contCap * sizeof(ContRec)); needL(ctx->contStacks, contCap * 16 * sizeof(uint32_t)); needL(ctx->contCount, 4 * kContShards * 32 * sizeof(uint32_t));   /* closest: 2 ping-pong counter arrays, any: 2 */
     needL(ctx->shadowRays, S * nL * sizeof(DRay)); needL(ctx->occluded, S * nL * 4); needL(ctx->lrec, S * nL * 16);
     need(ctx->counters, kCounterShards * sizeof(DeviceCounters));
+    if (pathMode) needL(ctx->pathAlive, kAliveShards * sizeof(uint32_t));
     if (!devFilm) need(ctx->film, (size_t)W * H * 5 * sizeof(float));
     if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? KKD_ERR_NOMEM : KKD_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
     float *film = devFilm ? devFilm : (float *)ctx->film.p;
@@ -416,6 +421,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     bp.g = g; bp.gShift = gShift; bp.chunks = chunks; bp.spp = rp->spp; bp.sampleFirst = rp->sample_first;
     bp.nB = nB; bp.nL = nL; bp.hideEmitters = rp->hide_emitters != 0;
     bp.integrator = rp->integrator; bp.strictNormals = rp->strict_normals != 0;
+    bp.maxDepth = rp->max_depth; bp.rrDepth = rp->rr_depth; bp.depth = 1;
     bp.chunksShift = 32; bp.pixShift = 32;
     if ((chunks & (chunks - 1)) == 0) { bp.chunksShift = 0; while ((1u << bp.chunksShift) < chunks) ++bp.chunksShift; }
     if ((bs & (bs - 1)) == 0) { bp.pixShift = 0; while ((1u << bp.pixShift) < bs * bs) ++bp.pixShift; }
@@ -426,7 +432,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     const bool count = (ctx->cfg.flags & KKD_FLAG_COUNT_TRAVERSAL) != 0;
     /* one event between consecutive kernels of a batch: 6 per batch, on the stream the kernels run on; events 0 / 1 bracket
      * the render on the context's stream, 2 forks and 3... join the other lanes */
-    const bool timeStages = stats != nullptr && nBatches <= 8192;
+    const bool timeStages = stats != nullptr && nBatches <= 8192 && !pathMode;   /* a path batch is a loop of stages: only the total is timed */
     const size_t evBase = 3 + kMaxLanes;
     const size_t nEvents = evBase + (timeStages ? (size_t)nBatches * 6 : 0);
     while (ctx->events.size() < nEvents) { hipEvent_t ev; KKD_HIP(ctx, hipEventCreate(&ev)); ctx->events.push_back(ev); }
@@ -471,6 +477,31 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         if (timeStages) hipEventRecord(ctx->events[ev++], st);
         if (bp.count == bp.stride) { trace(wb.shadowRays, (uint64_t)S * nL, true, wb.occluded, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++; }
         else for (uint32_t l = 0; l < nL; ++l) { trace(wb.shadowRays + (size_t)l * S, bp.count, true, (uint32_t *)wb.occluded + (size_t)l * S, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++; }
+        if (pathMode) {
+            /* MIPathTracer: vertices at depth 2, 3, ... -- kPathBounce resolves the segment just traced and shades the next
+             * vertex, then both ray kinds are traced again; kResolve adds the last segment.  The loop ends at maxDepth, or
+             * when no path of the batch is alive (read back from depth 4 on; Russian roulette ends every path). */
+            uint32_t *alive = (uint32_t *)laneP(ctx->pathAlive, kAliveShards * sizeof(uint32_t), lane);
+            for (uint32_t depth = 2; (rp->max_depth < 0 || (int)depth < rp->max_depth) && depth < 4096u; ++depth) {
+                bp.depth = depth;
+                static const bool noCheck = getenv("KKD_PATH_NOCHECK") != nullptr;   /* developer switch: never read the alive count back, stop at depth 64 */
+                if (noCheck && depth >= 64u) break;
+                const bool check = depth >= 4u && !noCheck;
+                if (check) hipMemsetAsync(alive, 0, kAliveShards * sizeof(uint32_t), st);
+                launchPathBounce(st, ctx->ds, bp, wb, alive); launches[KKD_STAGE_SHADE]++;
+                if (check) {
+                    uint32_t host[kAliveShards];
+                    KKD_HIP(ctx, hipMemcpyAsync(host, alive, sizeof(host), hipMemcpyDeviceToHost, st));
+                    KKD_HIP(ctx, hipStreamSynchronize(st));
+                    uint64_t n = 0; for (uint32_t k = 0; k < kAliveShards; ++k) n += host[k];
+                    if (n == 0) break;
+                }
+                trace(wb.bsdfRays, bp.count, false, wb.bsdfHits, KKD_RAYS_BSDF); launches[KKD_STAGE_BSDF]++;
+                trace(wb.shadowRays, bp.count, true, wb.occluded, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++;
+                if (ctx->cancel.load()) break;
+            }
+            bp.depth = 1;
+        }
         if (timeStages) hipEventRecord(ctx->events[ev++], st);
         launchResolve(st, ctx->ds, bp, wb, film, ctr); launches[KKD_STAGE_RESOLVE]++;
         if (timeStages) hipEventRecord(ctx->events[ev++], st);

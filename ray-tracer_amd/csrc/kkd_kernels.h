@@ -23,7 +23,9 @@ struct BatchParams {
      * group(w0) = (tile0 * bs^2 + pin0) * chunks + chunk0 */
     uint32_t chunk0, pin0, tile0, chunksShift /* log2(chunks) or 32 */, pixShift /* log2(bs^2) or 32 */;
     uint32_t nB, nL, hideEmitters;
-    uint32_t integrator, strictNormals;   /* KKD_INTEGRATOR_*; 'strictNormals' of the stock direct plugin */
+    uint32_t integrator, strictNormals;   /* KKD_INTEGRATOR_*; 'strictNormals' of the stock direct / path plugins */
+    int32_t maxDepth, rrDepth;            /* path plugin: 'maxDepth', 'rrDepth' */
+    uint32_t depth;                       /* path plugin: depth of the vertex a kPathBounce launch shades (2, 3, ...) */
     uint32_t bs, bsPow2, nbx, nby, tileIndex, tileCount, nTilesMine;
     int32_t W, H;
     uint32_t debug;                  /* developer ablation bits from $KKD_DEBUG: 1 = no film atomics, 2 = no BSDF-hit evaluation */
@@ -33,7 +35,7 @@ struct BatchParams {
 struct WaveBuffers {
     DHit *hits;          /* primary hits                       [stride]      */
     float4 *accum;       /* Le / environment + alpha           [stride]      */
-    float4 *refN;        /* DirectSamplingRecord::refN         [stride]      */
+    float4 *refN;        /* DirectSamplingRecord::refN; w = relative index of refraction along the path (path plugin) [stride] */
     DRay *bsdfRays;      /*                                    [nB * stride] */
     DHit *bsdfHits;      /*                                    [nB * stride] */
     float4 *brec0;       /* bsdf weight rgb, +-pdf (<0: delta) [nB * stride] */
@@ -59,6 +61,9 @@ struct TraceContinuation { ContRec *recs; uint4 *stacks; uint32_t *count; uint32
 void launchTracePhased(hipStream_t st, const DScene &sc, const DRay *rays, uint64_t n, bool anyHit, bool count, void *out, DeviceCounters *ctr,
                        int rayClass, const TraceContinuation &cont);
 void launchShade(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb);
+/* path plugin: resolve the segment traced last, play Russian roulette, shade the vertex at bp.depth; alive: kAliveShards counters of paths that go on */
+static constexpr uint32_t kAliveShards = 64;
+void launchPathBounce(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb, uint32_t *alive);
 void launchDevelop(hipStream_t st, const float *film, uint64_t nPixels, int pixelFormat, float *out);
 void launchResolve(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb, float *film, DeviceCounters *ctr);
 

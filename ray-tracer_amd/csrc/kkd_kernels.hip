@@ -262,9 +262,11 @@ __global__ void __launch_bounds__(256, 4) kShade(DScene sc, BatchParams bp, Wave
     /* sibling integrator on the same kernels: MIDirectIntegrator::Li (integrators/direct/direct.cpp:176-311) draws the
      * emitter samples before the BSDF samples, applies the geometric-normal tests only with 'strictNormals', samples
      * emitters only for smooth BSDFs and weights with the power heuristic */
-    const bool stock = bp.integrator == KKD_INTEGRATOR_DIRECT;
+    const bool stock = bp.integrator != KKD_INTEGRATOR_KK;      /* the path plugin's first vertex is the direct plugin's with one sample each */
     const bool geoTest = !stock || bp.strictNormals;
-    const bool dead = stock && bp.strictNormals && dot(its.geoN, rd) * its.wi.z >= 0.f;   /* direct.cpp:177-190 */
+    const bool dead = (stock && bp.strictNormals && dot(its.geoN, rd) * its.wi.z >= 0.f)   /* direct.cpp:177-190, path.cpp:156-165 */
+                      || (bp.integrator == KKD_INTEGRATOR_PATH && bp.maxDepth == 1);
+    float pathEta = 1.0f;
 
     /* integrateBrdf :74-104 -- the part before the ray is traced */
     for (uint32_t b = 0; b < nB; ++b) {
@@ -279,12 +281,13 @@ __global__ void __launch_bounds__(256, 4) kShade(DScene sc, BatchParams bp, Wave
                 r.ox = its.p.x; r.oy = its.p.y; r.oz = its.p.z; r.mint = kEpsilon;
                 r.dx = wo.x; r.dy = wo.y; r.dz = wo.z; r.maxt = kInf;
                 rec = make_float4(bsdfVal.x, bsdfVal.y, bsdfVal.z, (sampledType & EDelta) ? -bsdfPdf : bsdfPdf);
+                if (sampledType == EDeltaTransmission) { const float e = sc.materials[its.material].eta; pathEta = its.wi.z > 0.f ? e : frcp(e); }   /* bRec.eta, dielectric.cpp:300-308 */
             }
         }
         storeRay(wb.bsdfRays + (size_t)b * bp.stride + i, r);
         wb.brec0[(size_t)b * bp.stride + i] = rec;
     }
-    wb.refN[i] = make_float4(refN.x, refN.y, refN.z, 0.f);
+    wb.refN[i] = make_float4(refN.x, refN.y, refN.z, pathEta);
 
     /* integrateLight :127-160 -- everything but the visibility test, already MIS-weighted (:172-177) */
     for (uint32_t l = 0; l < nL; ++l) {
@@ -313,6 +316,118 @@ __global__ void __launch_bounds__(256, 4) kShade(DScene sc, BatchParams bp, Wave
         wb.lrec[(size_t)l * bp.stride + i] = rec;
     }
     wb.accum[i] = accum;
+}
+
+/* ---- K4b: next vertex of the path plugin (MIPathTracer::Li, integrators/path/path.cpp:135-287) -------------------------------
+ * One launch per depth >= 2, after the BSDF and shadow rays of the previous vertex have been traced: adds the emitter
+ * sample of the previous vertex if unoccluded, the emitter (or environment) the BSDF ray reached with its MIS weight
+ * (:226-264), plays Russian roulette (:276-286), then shades the vertex the BSDF ray hit exactly like kShade does for the
+ * first one: emitter sample (:172-200) and BSDF sample (:206-225), both scaled by the path throughput.  Paths that ended
+ * keep dead rays and zero records, so later launches and kResolve add nothing for them.  Sample dimensions of the vertex
+ * at depth d: 2 + 6 (d - 1) emitter sample, + 2 BSDF sample, + 4 Russian roulette (after that vertex). */
+__global__ void __launch_bounds__(256, 4) kPathBounce(DScene sc, BatchParams bp, WaveBuffers wb, uint32_t *__restrict__ alive) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    bool goesOn = false;
+    if (i < bp.count) {
+        const SampleId s = mapWorkItem(bp, i);
+        float4 acc = wb.accum[i];
+        {   /* emitter sample of the previous vertex */
+            const float4 lr = wb.lrec[i];
+            if (wb.occluded[i] == 0u) { acc.x += lr.x; acc.y += lr.y; acc.z += lr.z; }
+        }
+        const float4 rec = wb.brec0[i];
+        DRay nr, sr; killRay(nr); killRay(sr);
+        float4 nrec = make_float4(0.f, 0.f, 0.f, 0.f), nl = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s.active && rec.w != 0.f) {
+            DHit h = wb.bsdfHits[i];
+            const DRay r = wb.bsdfRays[i];
+            const float4 rn = wb.refN[i];
+            const f3 rd(r.dx, r.dy, r.dz);
+            f3 T(rec.x, rec.y, rec.z);
+            float eta = rn.w;
+            const float bsdfPdf = fabsf(rec.w);
+            DirectRec dRec; dRec.ref = f3(r.ox, r.oy, r.oz); dRec.refN = f3(rn.x, rn.y, rn.z); dRec.emitter = -1;
+            Its its;
+            bool cont = true, hitEmitter = false;
+            f3 value(0.f);
+            if (h.id == kNoHit) {                                                        /* :233-248 */
+                cont = false;
+                if (sc.envEmitter >= 0) {
+                    value = envEval(sc.env, rd);
+                    const f3 center(sc.env.center[0], sc.env.center[1], sc.env.center[2]);
+                    float nearT, farT;
+                    if (sphereRayIntersect(center, sc.env.radius, dRec.ref, rd, nearT, farT) && !(nearT > 0.f) && !(farT < 0.f)) {
+                        dRec.p = dRec.ref + rd * farT; dRec.n = normalize(center - dRec.p); dRec.measure = 0; dRec.emitter = sc.envEmitter;
+                        dRec.d = rd; dRec.dist = farT;
+                        hitEmitter = true;
+                    }
+                }
+            } else {                                                                     /* :226-232 */
+                h.id &= ~kHitNotEmitter;
+                fillIntersection<true>(sc, rd, h, its);
+                if (its.emitter >= 0) {
+                    value = areaEval(sc.emitters[its.emitter], its.sh.n, -rd);
+                    dRec.p = its.p; dRec.n = its.sh.n; dRec.d = rd; dRec.dist = h.t; dRec.measure = 0; dRec.emitter = its.emitter;
+                    hitEmitter = true;
+                }
+            }
+            if (hitEmitter) {                                                            /* :257-264 */
+                const float lumPdf = rec.w > 0.f ? pdfEmitterDirect(sc, dRec) : 0.f;
+                const float w = fdiv(bsdfPdf * bsdfPdf, bsdfPdf * bsdfPdf + lumPdf * lumPdf);
+                const f3 c = T * value * w;
+                acc.x += c.x; acc.y += c.y; acc.z += c.z;
+            }
+            if (cont && (int)bp.depth - 1 >= bp.rrDepth) {                               /* :276-286, depth before the increment */
+                const float q = fminf(maxComp(T) * eta * eta, 0.95f);
+                const f2 u = sample2D(bp.seed, s.pixel, s.sample, 2u + 6u * (bp.depth - 2u) + 4u);
+                if (u.x >= q) cont = false; else T = T / q;
+            }
+            if (cont && ((bp.maxDepth > 0 && (int)bp.depth >= bp.maxDepth) || (bp.strictNormals && dot(rd, its.geoN) * its.wi.z >= 0.f))) cont = false;   /* :156-165 */
+            if (cont) {
+                const uint32_t dim0 = 2u + 6u * (bp.depth - 1u);
+                const uint32_t btype = sc.materials[its.material].typeFlags;
+                const f3 refN = (btype & (ETransmission | EBackSide)) ? f3(0.f) : its.sh.n;
+                if ((btype & ESmooth) != 0u && sc.nEmitters) {                           /* :172-200 */
+                    const f2 u = sample2D(bp.seed, s.pixel, s.sample, dim0);
+                    DirectRec lRec; lRec.ref = its.p; lRec.refN = refN; lRec.emitter = -1;
+                    const f3 lval = sampleEmitterDirectUnoccluded(sc, lRec, u);
+                    if (!isZero(lval)) {
+                        const f3 woLocal = its.sh.toLocal(lRec.d);
+                        const f3 bsdfVal = evalBsdf(sc, its.material, its.wi, woLocal);
+                        if (!isZero(bsdfVal) && (!bp.strictNormals || dot(its.geoN, lRec.d) * woLocal.z > 0.f)) {
+                            const bool onSurface = sc.emitters[lRec.emitter].type != KKD_EMITTER_POINT;
+                            const float bp2 = onSurface ? pdfBsdf(sc, its.material, its.wi, woLocal) : 0.f;
+                            const float w = fdiv(lRec.pdf * lRec.pdf, lRec.pdf * lRec.pdf + bp2 * bp2);
+                            const f3 c = T * lval * bsdfVal * w;
+                            nl = make_float4(c.x, c.y, c.z, 0.f);
+                            sr.ox = its.p.x; sr.oy = its.p.y; sr.oz = its.p.z; sr.mint = kEpsilon;
+                            sr.dx = lRec.d.x; sr.dy = lRec.d.y; sr.dz = lRec.d.z; sr.maxt = lRec.dist * (1.f - kShadowEpsilon);
+                        }
+                    }
+                }
+                const f2 u = sample2D(bp.seed, s.pixel, s.sample, dim0 + 2u);             /* :206-225 */
+                f3 woLocal; float pdf; uint32_t sampledType;
+                const f3 bsdfWeight = sampleBsdf(sc, its.material, its.wi, u, woLocal, pdf, sampledType);
+                if (!isZero(bsdfWeight)) {
+                    const f3 wo = its.sh.toWorld(woLocal);
+                    if (!bp.strictNormals || dot(its.geoN, wo) * woLocal.z > 0.f) {
+                        nr.ox = its.p.x; nr.oy = its.p.y; nr.oz = its.p.z; nr.mint = kEpsilon;
+                        nr.dx = wo.x; nr.dy = wo.y; nr.dz = wo.z; nr.maxt = kInf;
+                        const f3 nT = T * bsdfWeight;                                     /* :252-253 */
+                        nrec = make_float4(nT.x, nT.y, nT.z, (sampledType & EDelta) ? -pdf : pdf);
+                        if (sampledType == EDeltaTransmission) { const float e = sc.materials[its.material].eta; eta *= its.wi.z > 0.f ? e : frcp(e); }
+                        wb.refN[i] = make_float4(refN.x, refN.y, refN.z, eta);
+                        goesOn = true;
+                    }
+                }
+            }
+        }
+        wb.accum[i] = acc;
+        storeRay(wb.bsdfRays + i, nr); wb.brec0[i] = nrec;
+        storeRay(wb.shadowRays + i, sr); wb.lrec[i] = nl;
+    }
+    const unsigned long long m = __ballot(goesOn);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(alive + (blockIdx.x % kAliveShards), (uint32_t)__popcll(m));
 }
 
 /* ---- filtered splat of the G samples a lane group holds of one pixel (ImageBlock::put, reduced across the group) -----------------------
@@ -430,7 +545,7 @@ __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveB
             const float bsdfPdf = fabsf(rec.w);
             const float lightPdf = rec.w > 0.f ? pdfEmitterDirect(sc, dRec) : 0.f;
             const float pa = cB * bsdfPdf, pb = cL * lightPdf;
-            const float weight = bp.integrator == KKD_INTEGRATOR_DIRECT ? fdiv(pa * pa, pa * pa + pb * pb) : fdiv(pa, pa + pb);   /* direct.cpp:303-305 */
+            const float weight = bp.integrator != KKD_INTEGRATOR_KK ? fdiv(pa * pa, pa * pa + pb * pb) : fdiv(pa, pa + pb);   /* direct.cpp:303-305, path.cpp:263 */
             L += value * f3(rec.x, rec.y, rec.z) * (weight * invNB);
         }
         for (uint32_t l = 0; l < nL; ++l) {
@@ -600,6 +715,10 @@ void launchTracePhased(hipStream_t st, const DScene &sc, const DRay *rays, uint6
 
 void launchShade(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb) {
     hipLaunchKernelGGL(kShade, dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, wb);
+}
+
+void launchPathBounce(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb, uint32_t *alive) {
+    hipLaunchKernelGGL(kPathBounce, dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, wb, alive);
 }
 
 void launchDevelop(hipStream_t st, const float *film, uint64_t n, int fmt, float *out) {

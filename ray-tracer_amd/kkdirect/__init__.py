@@ -91,25 +91,25 @@ class Context:
 
     @staticmethod
     def _params(spp, bsdf_samples, light_samples, hide_emitters, block_size, tile_index, tile_count, sample_first,
-                integrator=abi.INTEGRATOR_KK, strict_normals=False):
+                integrator=abi.INTEGRATOR_KK, strict_normals=False, max_depth=-1, rr_depth=5):
         return abi.RenderParams(spp, bsdf_samples, light_samples, int(hide_emitters), block_size, tile_index, tile_count, sample_first,
-                                integrator, int(strict_normals))
+                                integrator, int(strict_normals), max_depth, rr_depth)
 
     def render(self, spp, bsdf_samples=1, light_samples=1, hide_emitters=False, block_size=0, tile_index=0, tile_count=1,
-               sample_first=0, integrator=abi.INTEGRATOR_KK, strict_normals=False):
+               sample_first=0, integrator=abi.INTEGRATOR_KK, strict_normals=False, max_depth=-1, rr_depth=5):
         """-> (film[H, W, 5] float32 = {R*w, G*w, B*w, alpha*w, w}, abi.Stats)"""
         p = self._params(spp, bsdf_samples, light_samples, hide_emitters, block_size, tile_index, tile_count, sample_first,
-                         integrator, strict_normals)
+                         integrator, strict_normals, max_depth, rr_depth)
         film = np.zeros((self.height, self.width, 5), np.float32)
         st = abi.Stats()
         self._check(self.lib.kkd_render(self.h, C.byref(p), film.ctypes.data_as(abi.pf32), C.byref(st)))
         return film, st
 
     def render_device(self, dev_ptr, spp, bsdf_samples=1, light_samples=1, hide_emitters=False, block_size=0, tile_index=0,
-                      tile_count=1, sample_first=0, integrator=abi.INTEGRATOR_KK, strict_normals=False):
+                      tile_count=1, sample_first=0, integrator=abi.INTEGRATOR_KK, strict_normals=False, max_depth=-1, rr_depth=5):
         """Render into caller-owned device memory (H*W*5 floats, e.g. tensor.data_ptr()); -> abi.Stats"""
         p = self._params(spp, bsdf_samples, light_samples, hide_emitters, block_size, tile_index, tile_count, sample_first,
-                         integrator, strict_normals)
+                         integrator, strict_normals, max_depth, rr_depth)
         st = abi.Stats()
         self._check(self.lib.kkd_render_device(self.h, C.byref(p), C.c_void_p(dev_ptr), C.byref(st)))
         return st
@@ -332,6 +332,49 @@ class MIDirectIntegrator:
         try:
             return ctx.render(spp, self.bsdfSamples, self.emitterSamples, self.hideEmitters, integrator=abi.INTEGRATOR_DIRECT,
                               strict_normals=self.strictNormals, **kw)
+        finally:
+            if own:
+                ctx.close()
+
+
+class MIPathTracer:
+    """Host mirror of the stock 'path' plugin (reference src/integrators/path/path.cpp:110-118), the next sibling on the same
+    kernels: parameters of MonteCarloIntegrator (src/librender/integrator.cpp:190-233) -- rrDepth (5),
+    maxDepth (-1 = unbounded), strictNormals, hideEmitters."""
+    PLUGIN_NAME = "path"
+    DESCRIPTION = "MI path tracer"
+
+    def __init__(self, props=None, **kw):
+        props = dict(props or {}, **kw)
+        self.rrDepth = int(props.pop("rrDepth", 5))
+        self.maxDepth = int(props.pop("maxDepth", -1))
+        self.strictNormals = bool(props.pop("strictNormals", False))
+        self.hideEmitters = bool(props.pop("hideEmitters", False))
+        if props:
+            raise ValueError("path: unreferenced properties %s" % sorted(props))
+        if self.rrDepth <= 0:
+            raise ValueError("'rrDepth' must be set to a value greater than zero!")                      # integrator.cpp:220-221
+        if self.maxDepth <= 0 and self.maxDepth != -1:
+            raise ValueError("'maxDepth' must be set to -1 (infinite) or a value greater than zero!")    # integrator.cpp:223-224
+
+    def serialize(self):
+        """Field order of MonteCarloIntegrator::serialize (librender/integrator.cpp:229-241): int, int, bool, bool."""
+        import struct
+        return struct.pack("<ii??", self.rrDepth, self.maxDepth, self.strictNormals, self.hideEmitters)
+
+    @classmethod
+    def unserialize(cls, blob):
+        import struct
+        r, m, s, h = struct.unpack("<ii??", blob)
+        return cls(rrDepth=r, maxDepth=m, strictNormals=s, hideEmitters=h)
+
+    def render(self, scene, spp, device=0, seed=1, ctx=None, **kw):
+        own = ctx is None
+        if own:
+            ctx = Context(device=device, seed=seed).upload(scene)
+        try:
+            return ctx.render(spp, 1, 1, self.hideEmitters, integrator=abi.INTEGRATOR_PATH, strict_normals=self.strictNormals,
+                              max_depth=self.maxDepth, rr_depth=self.rrDepth, **kw)
         finally:
             if own:
                 ctx.close()

@@ -73,10 +73,10 @@ class Config(C.Structure):
 class RenderParams(C.Structure):
     _fields_ = [("spp", u32), ("bsdf_samples", u32), ("light_samples", u32), ("hide_emitters", i32),
                 ("block_size", u32), ("tile_index", u32), ("tile_count", u32), ("sample_first", u32),
-                ("integrator", u32), ("strict_normals", i32)]
+                ("integrator", u32), ("strict_normals", i32), ("max_depth", i32), ("rr_depth", i32)]
 
 
-INTEGRATOR_KK, INTEGRATOR_DIRECT = 0, 1
+INTEGRATOR_KK, INTEGRATOR_DIRECT, INTEGRATOR_PATH = 0, 1, 2
 
 
 class Stats(C.Structure):
