@@ -66,6 +66,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--leaf-test", default="watertight", choices=["watertight", "projection"],
                     help="projection = KKD_FLAG_PROJECTION_TEST (the reference's TriAccel arithmetic, bit-identical hit ids)")
+    ap.add_argument("--integrator", default="kk", choices=["kk", "direct", "path"],
+                    help="kk = the headline path; direct / path = the sibling plugins on the same kernels (not the headline metric)")
+    ap.add_argument("--max-depth", type=int, default=-1, help="path: maxDepth")
+    ap.add_argument("--rr-depth", type=int, default=5, help="path: rrDepth")
     ap.add_argument("--batch", type=int, default=0, help="camera samples in flight per batch (0 = library default)")
     args = ap.parse_args()
 
@@ -109,6 +113,10 @@ def main():
         kw = dict(spp=spp * world, tile_index=rank, tile_count=world, sample_first=0)
     else:
         kw = dict(spp=spp, tile_index=0, tile_count=1, sample_first=rank * spp)
+    if args.integrator != "kk":
+        kw.update(integrator={"direct": abi.INTEGRATOR_DIRECT, "path": abi.INTEGRATOR_PATH}[args.integrator])
+        if args.integrator == "path":
+            kw.update(max_depth=args.max_depth, rr_depth=args.rr_depth)
 
     def step():
         st = ctx.render_device(film.data_ptr(), bsdf_samples=n_b, light_samples=n_l, **kw)
@@ -147,7 +155,7 @@ def main():
         # ---- roofline of the dominant kernel: HIP-event stage times of the timed steps (recorded by the library on
         # the stream its kernels run on) against algorithmic bytes from a counting pass of the same traversal ----
         cctx = kkdirect.Context(device=local_rank, seed=1, count_traversal=True, projection_test=proj).upload(scene)
-        _, cst = cctx.render(min(spp, 8), n_b, n_l, tile_index=kw["tile_index"], tile_count=kw["tile_count"])
+        _, cst = cctx.render(min(spp, 8), n_b, n_l, **{k: v for k, v in kw.items() if k not in ("spp", "sample_first")})
         cctx.close()
         per_ray = [(cst.class_nodes[k] / max(1, cst.class_rays[k]), cst.class_tris[k] / max(1, cst.class_rays[k])) for k in range(3)]
         # In the timed region two batches of camera samples are in flight on two streams, so a kernel's event duration
@@ -165,7 +173,7 @@ def main():
         stage_n = [sum(s.stage_launches[k] for s in xstats) for k in range(5)]
         acc = ctx.accel_info()
         bytes_k = [sum(stage_bytes(s, n_b, n_l, per_ray, acc["node_bytes"], acc["tri_bytes"])[k] for s in xstats) for k in range(5)]
-        dom = int(np.argmax(stage_s))
+        dom = int(np.argmax(stage_s)) if sum(stage_s) > 0 else 2    # the path plugin times the render only, not its stages
         avg_launch_s = stage_s[dom] / max(1, stage_n[dom])
         achieved = bytes_k[dom] / max(1, stage_n[dom]) / max(avg_launch_s, 1e-12) / 1e9
         traffic = None
@@ -195,11 +203,12 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(scene, n_b, n_l, W, H)
         out = {
-            "metric": "Msamples/s (kk direct integrator)", "value": round(samples / elapsed / 1e6, 3), "unit": "Msamples/s",
+            "metric": "Msamples/s (kk direct integrator)" if args.integrator == "kk" else "Msamples/s (%s plugin, not the headline metric)" % args.integrator, "value": round(samples / elapsed / 1e6, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "mrays_per_s": round(rays / elapsed / 1e6, 3),
             "config": {"workload": label, "spp_total": kw["spp"] if args.split == "tile" else spp * world, "bsdfSamples": n_b, "lightSamples": n_l,
+                       "integrator": args.integrator, "max_depth": args.max_depth if args.integrator == "path" else None,
                        "split": args.split, "backend": backend, "leaf_test": args.leaf_test, "triangles": int(scene._nt), "scene_upload_s": round(upload_s, 2)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
