@@ -46,7 +46,7 @@ struct Microfacet {
                                                : fdiv(m.x * m.x, alphaU * alphaU) + fdiv(m.y * m.y, alphaV * alphaV)) * frcp(cosTheta2);
         float result;
         if (type == KKD_DISTR_BECKMANN) {
-            result = fdiv(expf(-beckmannExponent), kPi * alphaU * alphaV * cosTheta2 * cosTheta2);
+            result = fdiv(fexp(-beckmannExponent), kPi * alphaU * alphaV * cosTheta2 * cosTheta2);
         } else if (type == KKD_DISTR_GGX) {
             float root = (1.0f + beckmannExponent) * cosTheta2;
             result = frcp(kPi * alphaU * alphaV * root * root);
@@ -119,7 +119,8 @@ struct Microfacet {
         float sinThetaM = fsqrt(fmaxf(0.f, 1.f - cosThetaM * cosThetaM));
         return f3(sinThetaM * cosPhiM, sinThetaM * sinPhiM, cosThetaM);
     }
-    __device__ f2 sampleVisible11(float thetaI, f2 sample) const {
+    /* tanThetaI = tan(thetaI) is handed in: the caller has cos(thetaI), and sqrt(1 - c^2) / c is 3 instructions where tanf is ~80 */
+    __device__ f2 sampleVisible11(float thetaI, float tanThetaI, f2 sample) const {
         const float SQRT_PI_INV = 0.56418958354775628f;
         f2 slope;
         if (type == KKD_DISTR_BECKMANN) {
@@ -128,17 +129,17 @@ struct Microfacet {
                 sincosf(2.f * kPi * sample.y, &s, &c);
                 return f2{ r * c, r * s };
             }
-            float tanThetaI = tanf(thetaI), cotThetaI = frcp(tanThetaI);
+            float cotThetaI = frcp(tanThetaI);
             float a = -1.f, c = erfApprox(cotThetaI);
             float sample_x = fmaxf(sample.x, 1e-6f);
             float fit = 1.f + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
-            float b = c - (1.f + c) * powf(1.f - sample_x, fit);
-            float normalization = frcp(1.f + c + SQRT_PI_INV * tanThetaI * expf(-cotThetaI * cotThetaI));
+            float b = c - (1.f + c) * fpow(1.f - sample_x, fit);
+            float normalization = frcp(1.f + c + SQRT_PI_INV * tanThetaI * fexp(-cotThetaI * cotThetaI));
             int it = 0;
             while (++it < 10) {
                 if (!(b >= a && b <= c)) b = 0.5f * (a + c);
                 float invErf = erfinvApprox(b);
-                float value = normalization * (1.f + b + SQRT_PI_INV * tanThetaI * expf(-invErf * invErf)) - sample_x;
+                float value = normalization * (1.f + b + SQRT_PI_INV * tanThetaI * fexp(-invErf * invErf)) - sample_x;
                 float derivative = normalization * (1.f - invErf * tanThetaI);
                 if (fabsf(value) < 1e-5f) break;
                 if (value > 0.f) c = b; else a = b;
@@ -152,7 +153,6 @@ struct Microfacet {
                 sincosf(2.f * kPi * sample.y, &s, &c);
                 return f2{ r * c, r * s };
             }
-            float tanThetaI = tanf(thetaI);
             float a = frcp(tanThetaI);
             float G1 = fdiv(2.0f, 1.0f + safeSqrt(1.0f + frcp(a * a)));
             float A = fdiv(2.0f * sample.x, G1) - 1.0f;
@@ -173,11 +173,16 @@ struct Microfacet {
     }
     __device__ f3 sampleVisibleNormal(f3 _wi, f2 sample) const {
         f3 wi = normalize(f3(alphaU * _wi.x, alphaV * _wi.y, _wi.z));
-        float theta = 0.f, phi = 0.f;
-        if (wi.z < 0.99999f) { theta = acosf(wi.z); phi = atan2f(wi.y, wi.x); }
-        float sinPhi, cosPhi;
-        sincosf(phi, &sinPhi, &cosPhi);
-        f2 slope = sampleVisible11(theta, sample);
+        /* microfacet.h:421-459 takes theta = acos(wi.z), phi = atan2(wi.y, wi.x) and then sin / cos / tan of them: the same
+         * numbers come straight from the components (cos phi = x / |xy|, tan theta = |xy| / z); only Beckmann's fit needs theta */
+        float theta = 0.f, tanTheta = 0.f, sinPhi = 0.f, cosPhi = 1.f;
+        if (wi.z < 0.99999f) {
+            const float s2 = wi.x * wi.x + wi.y * wi.y, r = frsq(s2);
+            cosPhi = wi.x * r; sinPhi = wi.y * r;
+            tanTheta = fdiv(s2 * r, wi.z);
+            theta = type == KKD_DISTR_BECKMANN ? acosf(wi.z) : 1.0f;   /* GGX only tests theta < 1e-4 */
+        }
+        f2 slope = sampleVisible11(theta, tanTheta, sample);
         slope = f2{ cosPhi * slope.x - sinPhi * slope.y, sinPhi * slope.x + cosPhi * slope.y };
         slope.x *= alphaU; slope.y *= alphaV;
         float normalization = frsq(slope.x * slope.x + slope.y * slope.y + 1.0f);
