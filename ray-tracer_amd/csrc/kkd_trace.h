@@ -246,28 +246,22 @@ __device__ __forceinline__ DHit traverse(const Node4 *__restrict__ nodes, const 
  * wstack: LDS, kMaxTraversalStack words owned by this wave.  Counters: a lane counts a child it hits (node or the
  * triangles of a leaf), i.e. what its own walk would have visited.
  */
-template <bool COUNT, bool PROJ>
-__device__ __forceinline__ DHit traversePacket(const WideNode *__restrict__ wnodes, const void *__restrict__ tris, const DRay &ray,
-                                               uint32_t *wstack, uint32_t &nNodes, uint32_t &nTris) {
-    DHit hit; hit.t = kInf; hit.u = 0.f; hit.v = 0.f; hit.id = kNoHit;
-    const float ox = ray.ox, oy = ray.oy, oz = ray.oz;
-    const float tmin = adaptiveMinT<false>(ray.mint, ox, oy, oz);
-    float tmax = ray.maxt;
-    if (!(tmax > tmin)) tmax = -1.0f;              /* dead lane: no box and no triangle is ever hit */
-    if (__ballot(tmax > tmin) == 0ull) return hit;
-    const float kBig = 0x1p100f, kTiny = 0x1p-100f;
-    const float idx = fabsf(ray.dx) < kTiny ? copysignf(kBig, ray.dx) : 1.0f / ray.dx;
-    const float idy = fabsf(ray.dy) < kTiny ? copysignf(kBig, ray.dy) : 1.0f / ray.dy;
-    const float idz = fabsf(ray.dz) < kTiny ? copysignf(kBig, ray.dz) : 1.0f / ray.dz;
-    WoopRay wr; wr.init(ray.dx, ray.dy, ray.dz);
-    const float4 *tris4 = reinterpret_cast<const float4 *>(tris);
-    if (COUNT) ++nNodes;                           /* the root */
+/* OCT: the sign octant of the ray directions when it is the same for every live lane of the wave (bit 0 / 1 / 2: x / y / z
+ * negative), 8 otherwise.  With a known octant the near and the far plane of every slab are known at compile time, so a
+ * child costs 6 fma + 2 max/max3 + 2 min/min3 instead of 6 more min / max -- same values, same walk, a third fewer VALU
+ * instructions in a kernel that is VALU-issue bound.  Primary rays of one pixel share their octant except across an axis. */
+template <bool COUNT, bool PROJ, int OCT>
+__device__ __forceinline__ void packetWalk(const WideNode *__restrict__ wnodes, const float4 *__restrict__ tris4, const DRay &ray, const WoopRay &wr,
+                                           float ox, float oy, float oz, float idx, float idy, float idz, float tmin, float &tmax,
+                                           uint32_t *wstack, DHit &hit, uint32_t &nNodes, uint32_t &nTris) {
     int sp = 0;
     uint32_t cur = 0;
     /* every wave leaves this loop: each iteration pops or descends in a finite tree; the step bound ends a malformed one */
     for (int guard = 1 << 24; guard > 0; --guard) {
         cur = __builtin_amdgcn_readfirstlane(cur);
         if (!(cur & kLeafBit)) {
+            /* (reading the record as eight 16-byte words up front instead was measured slower: 30.1 vs 28.9 ms; the scalar side
+             * of this loop, ~85 SALU instructions per node visit, bounds it together with the VALU side) */
             const WideNode *n = wnodes + cur;
             const float tbx = (n->ox - ox) * idx, tby = (n->oy - oy) * idy, tbz = (n->oz - oz) * idz;
             uint32_t dk[4], ck[4];
@@ -275,11 +269,20 @@ __device__ __forceinline__ DHit traversePacket(const WideNode *__restrict__ wnod
             for (int k = 0; k < 4; ++k) {
                 ck[k] = n->child[k]; dk[k] = 0xFFFFFFFFu;
                 if (ck[k] == 0u) continue;         /* empty slot (wave-uniform) */
-                const float t0x = fmaf(n->rminx[k], idx, tbx), t1x = fmaf(n->rmaxx[k], idx, tbx);
-                const float t0y = fmaf(n->rminy[k], idy, tby), t1y = fmaf(n->rmaxy[k], idy, tby);
-                const float t0z = fmaf(n->rminz[k], idz, tbz), t1z = fmaf(n->rmaxz[k], idz, tbz);
-                const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
-                const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+                float tn, tf;
+                if (OCT < 8) {
+                    const float nx = (OCT & 1) ? n->rmaxx[k] : n->rminx[k], fx = (OCT & 1) ? n->rminx[k] : n->rmaxx[k];
+                    const float ny = (OCT & 2) ? n->rmaxy[k] : n->rminy[k], fy = (OCT & 2) ? n->rminy[k] : n->rmaxy[k];
+                    const float nz = (OCT & 4) ? n->rmaxz[k] : n->rminz[k], fz = (OCT & 4) ? n->rminz[k] : n->rmaxz[k];
+                    tn = fmaxf(fmaxf(fmaf(nx, idx, tbx), fmaf(ny, idy, tby)), fmaxf(fmaf(nz, idz, tbz), tmin));
+                    tf = fminf(fminf(fmaf(fx, idx, tbx), fmaf(fy, idy, tby)), fminf(fmaf(fz, idz, tbz), tmax));
+                } else {
+                    const float t0x = fmaf(n->rminx[k], idx, tbx), t1x = fmaf(n->rmaxx[k], idx, tbx);
+                    const float t0y = fmaf(n->rminy[k], idy, tby), t1y = fmaf(n->rmaxy[k], idy, tby);
+                    const float t0z = fmaf(n->rminz[k], idz, tbz), t1z = fmaf(n->rmaxz[k], idz, tbz);
+                    tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
+                    tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+                }
                 const bool h = tn * 0.999999f <= tf * 1.000001f;
                 const unsigned long long m = __ballot(h);
                 if (COUNT && h) { if (ck[k] & kLeafBit) nTris += ((ck[k] >> 28) & 7u) + 1u; else ++nNodes; }
@@ -307,6 +310,36 @@ __device__ __forceinline__ DHit traversePacket(const WideNode *__restrict__ wnod
         if (sp == 0) break;
         cur = wstack[--sp];
     }
+}
+
+template <bool COUNT, bool PROJ>
+__device__ __forceinline__ DHit traversePacket(const WideNode *__restrict__ wnodes, const void *__restrict__ tris, const DRay &ray,
+                                               uint32_t *wstack, uint32_t &nNodes, uint32_t &nTris) {
+    DHit hit; hit.t = kInf; hit.u = 0.f; hit.v = 0.f; hit.id = kNoHit;
+    const float ox = ray.ox, oy = ray.oy, oz = ray.oz;
+    const float tmin = adaptiveMinT<false>(ray.mint, ox, oy, oz);
+    float tmax = ray.maxt;
+    if (!(tmax > tmin)) tmax = -1.0f;              /* dead lane: no box and no triangle is ever hit */
+    const unsigned long long live = __ballot(tmax > tmin);
+    if (live == 0ull) return hit;
+    const float kBig = 0x1p100f, kTiny = 0x1p-100f;
+    const float idx = fabsf(ray.dx) < kTiny ? copysignf(kBig, ray.dx) : 1.0f / ray.dx;
+    const float idy = fabsf(ray.dy) < kTiny ? copysignf(kBig, ray.dy) : 1.0f / ray.dy;
+    const float idz = fabsf(ray.dz) < kTiny ? copysignf(kBig, ray.dz) : 1.0f / ray.dz;
+    WoopRay wr; wr.init(ray.dx, ray.dy, ray.dz);
+    const float4 *tris4 = reinterpret_cast<const float4 *>(tris);
+    if (COUNT) ++nNodes;                           /* the root */
+    /* sign octant of the live lanes (a dead lane hits nothing whatever planes it is given) */
+    const unsigned long long mx = __ballot(idx < 0.f) & live, my = __ballot(idy < 0.f) & live, mz = __ballot(idz < 0.f) & live;
+    const bool uniform = (mx == 0ull || mx == live) && (my == 0ull || my == live) && (mz == 0ull || mz == live);
+    const int oct = uniform ? ((mx ? 1 : 0) | (my ? 2 : 0) | (mz ? 4 : 0)) : 8;
+#define KKD_PW(O) packetWalk<COUNT, PROJ, O>(wnodes, tris4, ray, wr, ox, oy, oz, idx, idy, idz, tmin, tmax, wstack, hit, nNodes, nTris)
+    switch (oct) {
+        case 0: KKD_PW(0); break; case 1: KKD_PW(1); break; case 2: KKD_PW(2); break; case 3: KKD_PW(3); break;
+        case 4: KKD_PW(4); break; case 5: KKD_PW(5); break; case 6: KKD_PW(6); break; case 7: KKD_PW(7); break;
+        default: KKD_PW(8); break;
+    }
+#undef KKD_PW
     return hit;
 }
 
