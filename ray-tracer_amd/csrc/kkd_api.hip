@@ -52,7 +52,7 @@ struct kkd_ctx {
     DevBuf nodes, wideNodes, tris, projTris, positions, normals, texcoords, indices, shapes, materials, emitters, emitterCdf, areaCdf, rtTables,
            envTexels, envCdfRows, envCdfCols, envRowWeights;
     /* work buffers */
-    DevBuf contRecs, contStacks, contCount, pathAlive;
+    DevBuf contRecs, contStacks, contCount, pathAlive, pBsdfRays, pBrec, pRefN, pShadowRays, pLrec, pSampleIdx;
     /* first-round step budgets of the round-based traversal; adapted from the share of rays the last batch parked */
     int capClosest = 28, capAny = 20;
     DevBuf hits, accum, refN, bsdfRays, bsdfHits, brec0, shadowRays, occluded, lrec, film, counters, apiRays, apiHits;
@@ -122,7 +122,8 @@ void kkd_destroy(kkd_ctx *ctx) {
     DevBuf *all[] = { &ctx->nodes, &ctx->wideNodes, &ctx->tris, &ctx->projTris, &ctx->positions, &ctx->normals, &ctx->texcoords, &ctx->indices, &ctx->shapes, &ctx->materials,
                       &ctx->emitters, &ctx->emitterCdf, &ctx->areaCdf, &ctx->rtTables, &ctx->envTexels, &ctx->envCdfRows, &ctx->envCdfCols,
                       &ctx->envRowWeights, &ctx->contRecs, &ctx->contStacks, &ctx->contCount, &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->shadowRays,
-                      &ctx->occluded, &ctx->lrec, &ctx->film, &ctx->counters, &ctx->apiRays, &ctx->apiHits };
+                      &ctx->occluded, &ctx->lrec, &ctx->film, &ctx->counters, &ctx->apiRays, &ctx->apiHits,
+                      &ctx->pathAlive, &ctx->pBsdfRays, &ctx->pBrec, &ctx->pRefN, &ctx->pShadowRays, &ctx->pLrec, &ctx->pSampleIdx };
     for (DevBuf *b : all) b->release();
     for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
     for (hipStream_t s : ctx->laneStreams) if (s) hipStreamDestroy(s);
@@ -393,7 +394,11 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     needL(ctx->contRecs, contCap * sizeof(ContRec)); needL(ctx->contStacks, contCap * 16 * sizeof(uint32_t)); needL(ctx->contCount, 4 * kContShards * 32 * sizeof(uint32_t));   /* closest: 2 ping-pong counter arrays, any: 2 */
     needL(ctx->shadowRays, S * nL * sizeof(DRay)); needL(ctx->occluded, S * nL * 4); needL(ctx->lrec, S * nL * 16);
     need(ctx->counters, kCounterShards * sizeof(DeviceCounters));
-    if (pathMode) needL(ctx->pathAlive, kAliveShards * sizeof(uint32_t));
+    if (pathMode) {   /* slot counters and the second set of path arrays (compaction ping-pong) */
+        needL(ctx->pathAlive, (kAliveShards + 1) * sizeof(uint32_t));
+        needL(ctx->pBsdfRays, S * sizeof(DRay)); needL(ctx->pBrec, S * 16); needL(ctx->pRefN, S * 16);
+        needL(ctx->pShadowRays, S * sizeof(DRay)); needL(ctx->pLrec, S * 16); needL(ctx->pSampleIdx, 2 * S * sizeof(uint32_t));
+    }
     if (!devFilm) need(ctx->film, (size_t)W * H * 5 * sizeof(float));
     if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? KKD_ERR_NOMEM : KKD_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
     float *film = devFilm ? devFilm : (float *)ctx->film.p;
@@ -409,6 +414,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         wb.brec0 = (float4 *)laneP(ctx->brec0, S * nB * 16, l);
         wb.shadowRays = (DRay *)laneP(ctx->shadowRays, S * nL * sizeof(DRay), l); wb.occluded = (uint32_t *)laneP(ctx->occluded, S * nL * 4, l);
         wb.lrec = (float4 *)laneP(ctx->lrec, S * nL * 16, l);
+        wb.sampleIdx = nullptr;
     }
     static const int capLater = [] { const char *e = getenv("KKD_ITER_CAP_LATER"); return e ? atoi(e) : 8; }();
     static const int rounds = [] { const char *e = getenv("KKD_TRACE_ROUNDS"); return e ? atoi(e) : 2; }();
@@ -478,29 +484,52 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         if (bp.count == bp.stride) { trace(wb.shadowRays, (uint64_t)S * nL, true, wb.occluded, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++; }
         else for (uint32_t l = 0; l < nL; ++l) { trace(wb.shadowRays + (size_t)l * S, bp.count, true, (uint32_t *)wb.occluded + (size_t)l * S, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++; }
         if (pathMode) {
-            /* MIPathTracer: vertices at depth 2, 3, ... -- kPathBounce resolves the segment just traced and shades the next
-             * vertex, then both ray kinds are traced again; kResolve adds the last segment.  The loop ends at maxDepth, or
-             * when no path of the batch is alive (read back from depth 4 on; Russian roulette ends every path). */
-            uint32_t *alive = (uint32_t *)laneP(ctx->pathAlive, kAliveShards * sizeof(uint32_t), lane);
-            for (uint32_t depth = 2; (rp->max_depth < 0 || (int)depth < rp->max_depth) && depth < 4096u; ++depth) {
+            /* MIPathTracer: vertices at depth 2, 3, ... -- kPathBounce resolves the segments just traced and shades the next
+             * vertices, then both ray kinds are traced again.  After every bounce the host reads back how many paths go on:
+             * the loop ends when none does (Russian roulette ends every path) or at maxDepth, and once fewer than three
+             * quarters of the slots are alive the next bounce writes the survivors densely into the other set of path
+             * arrays, so that later launches only cover live paths. */
+            uint32_t *counters = (uint32_t *)laneP(ctx->pathAlive, (kAliveShards + 1) * sizeof(uint32_t), lane);
+            WaveBuffers sets[2] = { wb, wb };
+            sets[1].bsdfRays = (DRay *)laneP(ctx->pBsdfRays, S * sizeof(DRay), lane); sets[1].brec0 = (float4 *)laneP(ctx->pBrec, S * 16, lane);
+            sets[1].refN = (float4 *)laneP(ctx->pRefN, S * 16, lane); sets[1].shadowRays = (DRay *)laneP(ctx->pShadowRays, S * sizeof(DRay), lane);
+            sets[1].lrec = (float4 *)laneP(ctx->pLrec, S * 16, lane);
+            sets[0].sampleIdx = (uint32_t *)laneP(ctx->pSampleIdx, 2 * S * sizeof(uint32_t), lane); sets[1].sampleIdx = sets[0].sampleIdx + S;
+            int cur = 0;
+            uint32_t n = bp.count;
+            bool identity = true, compactNext = false, everCompacted = false;
+            static const bool noCompact = getenv("KKD_PATH_NOCOMPACT") != nullptr;   /* developer switch (A/B runs) */
+            for (uint32_t depth = 2; (rp->max_depth < 0 || (int)depth < rp->max_depth) && depth < 4096u && n > 0; ++depth) {
                 bp.depth = depth;
-                static const bool noCheck = getenv("KKD_PATH_NOCHECK") != nullptr;   /* developer switch: never read the alive count back, stop at depth 64 */
-                if (noCheck && depth >= 64u) break;
-                const bool check = depth >= 4u && !noCheck;
-                if (check) hipMemsetAsync(alive, 0, kAliveShards * sizeof(uint32_t), st);
-                launchPathBounce(st, ctx->ds, bp, wb, alive); launches[KKD_STAGE_SHADE]++;
-                if (check) {
-                    uint32_t host[kAliveShards];
-                    KKD_HIP(ctx, hipMemcpyAsync(host, alive, sizeof(host), hipMemcpyDeviceToHost, st));
-                    KKD_HIP(ctx, hipStreamSynchronize(st));
-                    uint64_t n = 0; for (uint32_t k = 0; k < kAliveShards; ++k) n += host[k];
-                    if (n == 0) break;
-                }
-                trace(wb.bsdfRays, bp.count, false, wb.bsdfHits, KKD_RAYS_BSDF); launches[KKD_STAGE_BSDF]++;
-                trace(wb.shadowRays, bp.count, true, wb.occluded, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++;
+                KKD_HIP(ctx, hipMemsetAsync(counters, 0, (kAliveShards + 1) * sizeof(uint32_t), st));
+                PathLaunch pl; pl.nIn = n; pl.identity = identity; pl.compact = compactNext; pl.terminate = 0; pl.counters = counters;
+                launchPathBounce(st, ctx->ds, bp, sets[cur], sets[compactNext ? cur ^ 1 : cur], pl); launches[KKD_STAGE_SHADE]++;
+                uint32_t host[kAliveShards + 1];
+                KKD_HIP(ctx, hipMemcpyAsync(host, counters, sizeof(host), hipMemcpyDeviceToHost, st));
+                KKD_HIP(ctx, hipStreamSynchronize(st));
+                uint64_t alive = 0; for (uint32_t k = 0; k <= kAliveShards; ++k) alive += host[k];
+                if (compactNext) { cur ^= 1; n = (uint32_t)alive; everCompacted = true; }
+                identity = false;
+                if (alive == 0) { n = 0; break; }
+                compactNext = !noCompact && alive < (uint64_t)n * 3 / 4;
+                trace(sets[cur].bsdfRays, n, false, wb.bsdfHits, KKD_RAYS_BSDF); launches[KKD_STAGE_BSDF]++;
+                trace(sets[cur].shadowRays, n, true, wb.occluded, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++;
                 if (ctx->cancel.load()) break;
             }
+            if (!everCompacted) {
+                /* never compacted: slot j still holds sample j, so kResolve adds the last segments itself, as for the direct plugin */
+                bp.depth = 1;
+                launchResolve(st, ctx->ds, bp, wb, film, ctr); launches[KKD_STAGE_RESOLVE]++;
+                continue;
+            }
+            /* what the last segments found goes into the per-sample sums; kResolve then only splats them */
+            bp.depth = 0x7fffffff;
+            PathLaunch pl; pl.nIn = n; pl.identity = identity; pl.compact = 0; pl.terminate = 1; pl.counters = counters;
+            launchPathBounce(st, ctx->ds, bp, sets[cur], sets[cur], pl); launches[KKD_STAGE_SHADE]++;
             bp.depth = 1;
+            BatchParams bpSplat = bp; bpSplat.nB = 0; bpSplat.nL = 0;
+            launchResolve(st, ctx->ds, bpSplat, wb, film, ctr); launches[KKD_STAGE_RESOLVE]++;
+            continue;
         }
         if (timeStages) hipEventRecord(ctx->events[ev++], st);
         launchResolve(st, ctx->ds, bp, wb, film, ctr); launches[KKD_STAGE_RESOLVE]++;

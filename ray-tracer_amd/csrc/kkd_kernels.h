@@ -42,6 +42,7 @@ struct WaveBuffers {
     DRay *shadowRays;    /*                                    [nL * stride] */
     uint32_t *occluded;  /*                                    [nL * stride] */
     float4 *lrec;        /* MIS-weighted light contribution    [nL * stride] */
+    uint32_t *sampleIdx; /* path plugin: sample (index into accum) of the path in this slot [stride] */
 };
 
 void launchPrimary(hipStream_t st, bool count, const DScene &sc, const BatchParams &bp, DHit *hits, DeviceCounters *ctr);
@@ -63,7 +64,12 @@ void launchTracePhased(hipStream_t st, const DScene &sc, const DRay *rays, uint6
 void launchShade(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb);
 /* path plugin: resolve the segment traced last, play Russian roulette, shade the vertex at bp.depth; alive: kAliveShards counters of paths that go on */
 static constexpr uint32_t kAliveShards = 64;
-void launchPathBounce(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb, uint32_t *alive);
+/* One kPathBounce launch over the nIn path slots of `in`.  identity: slot j holds sample j (right after kShade).  compact:
+ * paths that go on (or still have a shadow ray pending) are written densely into `out` (other arrays than `in`), slots
+ * handed out through counters[kAliveShards]; otherwise every slot is rewritten in place (out == in) and the paths that go
+ * on are counted in counters[0 .. kAliveShards).  terminate: only add what the last segments found, shade nothing. */
+struct PathLaunch { uint32_t nIn, identity, compact, terminate; uint32_t *counters; };
+void launchPathBounce(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &in, const WaveBuffers &out, const PathLaunch &pl);
 void launchDevelop(hipStream_t st, const float *film, uint64_t nPixels, int pixelFormat, float *out);
 void launchResolve(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb, float *film, DeviceCounters *ctr);
 

@@ -322,26 +322,31 @@ __global__ void __launch_bounds__(256, 4) kShade(DScene sc, BatchParams bp, Wave
  * One launch per depth >= 2, after the BSDF and shadow rays of the previous vertex have been traced: adds the emitter
  * sample of the previous vertex if unoccluded, the emitter (or environment) the BSDF ray reached with its MIS weight
  * (:226-264), plays Russian roulette (:276-286), then shades the vertex the BSDF ray hit exactly like kShade does for the
- * first one: emitter sample (:172-200) and BSDF sample (:206-225), both scaled by the path throughput.  Paths that ended
- * keep dead rays and zero records, so later launches and kResolve add nothing for them.  Sample dimensions of the vertex
- * at depth d: 2 + 6 (d - 1) emitter sample, + 2 BSDF sample, + 4 Russian roulette (after that vertex). */
-__global__ void __launch_bounds__(256, 4) kPathBounce(DScene sc, BatchParams bp, WaveBuffers wb, uint32_t *__restrict__ alive) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    bool goesOn = false;
-    if (i < bp.count) {
+ * first one: emitter sample (:172-200) and BSDF sample (:206-225), both scaled by the path throughput.  Path state lives
+ * in slots (rays, records, refN + eta, sample index); radiance is summed per sample in accum.  A launch either rewrites its
+ * slots in place (ended paths get dead rays and zero records) or, `compact`, writes the paths that go on densely into the
+ * other set of arrays.  Sample dimensions of the vertex at depth d: 2 + 6 (d - 1) emitter sample, + 2 BSDF sample, + 4
+ * Russian roulette (after that vertex). */
+__global__ void __launch_bounds__(256, 4) kPathBounce(DScene sc, BatchParams bp, WaveBuffers wb, WaveBuffers wo, PathLaunch pl) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = j < pl.nIn;
+    bool goesOn = false, need = false;
+    uint32_t i = 0;
+    DRay nr, sr; killRay(nr); killRay(sr);
+    float4 nrec = make_float4(0.f, 0.f, 0.f, 0.f), nl = make_float4(0.f, 0.f, 0.f, 0.f), nrefN = make_float4(0.f, 0.f, 0.f, 1.f);
+    if (valid) {
+        i = pl.identity ? j : wb.sampleIdx[j];
         const SampleId s = mapWorkItem(bp, i);
         float4 acc = wb.accum[i];
         {   /* emitter sample of the previous vertex */
-            const float4 lr = wb.lrec[i];
-            if (wb.occluded[i] == 0u) { acc.x += lr.x; acc.y += lr.y; acc.z += lr.z; }
+            const float4 lr = wb.lrec[j];
+            if (wb.occluded[j] == 0u) { acc.x += lr.x; acc.y += lr.y; acc.z += lr.z; }
         }
-        const float4 rec = wb.brec0[i];
-        DRay nr, sr; killRay(nr); killRay(sr);
-        float4 nrec = make_float4(0.f, 0.f, 0.f, 0.f), nl = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 rec = wb.brec0[j];
         if (s.active && rec.w != 0.f) {
-            DHit h = wb.bsdfHits[i];
-            const DRay r = wb.bsdfRays[i];
-            const float4 rn = wb.refN[i];
+            DHit h = wb.bsdfHits[j];
+            const DRay r = wb.bsdfRays[j];
+            const float4 rn = wb.refN[j];
             const f3 rd(r.dx, r.dy, r.dz);
             f3 T(rec.x, rec.y, rec.z);
             float eta = rn.w;
@@ -377,6 +382,7 @@ __global__ void __launch_bounds__(256, 4) kPathBounce(DScene sc, BatchParams bp,
                 const f3 c = T * value * w;
                 acc.x += c.x; acc.y += c.y; acc.z += c.z;
             }
+            if (pl.terminate) cont = false;
             if (cont && (int)bp.depth - 1 >= bp.rrDepth) {                               /* :276-286, depth before the increment */
                 const float q = fminf(maxComp(T) * eta * eta, 0.95f);
                 const f2 u = sample2D(bp.seed, s.pixel, s.sample, 2u + 6u * (bp.depth - 2u) + 4u);
@@ -387,6 +393,7 @@ __global__ void __launch_bounds__(256, 4) kPathBounce(DScene sc, BatchParams bp,
                 const uint32_t dim0 = 2u + 6u * (bp.depth - 1u);
                 const uint32_t btype = sc.materials[its.material].typeFlags;
                 const f3 refN = (btype & (ETransmission | EBackSide)) ? f3(0.f) : its.sh.n;
+                nrefN = make_float4(refN.x, refN.y, refN.z, eta);
                 if ((btype & ESmooth) != 0u && sc.nEmitters) {                           /* :172-200 */
                     const f2 u = sample2D(bp.seed, s.pixel, s.sample, dim0);
                     DirectRec lRec; lRec.ref = its.p; lRec.refN = refN; lRec.emitter = -1;
@@ -402,6 +409,7 @@ __global__ void __launch_bounds__(256, 4) kPathBounce(DScene sc, BatchParams bp,
                             nl = make_float4(c.x, c.y, c.z, 0.f);
                             sr.ox = its.p.x; sr.oy = its.p.y; sr.oz = its.p.z; sr.mint = kEpsilon;
                             sr.dx = lRec.d.x; sr.dy = lRec.d.y; sr.dz = lRec.d.z; sr.maxt = lRec.dist * (1.f - kShadowEpsilon);
+                            need = true;
                         }
                     }
                 }
@@ -415,19 +423,34 @@ __global__ void __launch_bounds__(256, 4) kPathBounce(DScene sc, BatchParams bp,
                         nr.dx = wo.x; nr.dy = wo.y; nr.dz = wo.z; nr.maxt = kInf;
                         const f3 nT = T * bsdfWeight;                                     /* :252-253 */
                         nrec = make_float4(nT.x, nT.y, nT.z, (sampledType & EDelta) ? -pdf : pdf);
-                        if (sampledType == EDeltaTransmission) { const float e = sc.materials[its.material].eta; eta *= its.wi.z > 0.f ? e : frcp(e); }
-                        wb.refN[i] = make_float4(refN.x, refN.y, refN.z, eta);
-                        goesOn = true;
+                        if (sampledType == EDeltaTransmission) { const float e = sc.materials[its.material].eta; nrefN.w = eta * (its.wi.z > 0.f ? e : frcp(e)); }
+                        goesOn = true; need = true;
                     }
                 }
             }
         }
         wb.accum[i] = acc;
-        storeRay(wb.bsdfRays + i, nr); wb.brec0[i] = nrec;
-        storeRay(wb.shadowRays + i, sr); wb.lrec[i] = nl;
     }
-    const unsigned long long m = __ballot(goesOn);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(alive + (blockIdx.x % kAliveShards), (uint32_t)__popcll(m));
+    if (pl.terminate) return;
+    const unsigned long long m = __ballot(need);
+    uint32_t slot = j;
+    if (pl.compact) {
+        /* dense slots for the paths that go on: one atomic per block on the slot counter */
+        __shared__ uint32_t waveCount[4], blockBase;
+        const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+        if (lane == 0) waveCount[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) { const uint32_t total = waveCount[0] + waveCount[1] + waveCount[2] + waveCount[3]; blockBase = total ? atomicAdd(pl.counters + kAliveShards, total) : 0u; }
+        __syncthreads();
+        uint32_t base = blockBase;
+        for (uint32_t w = 0; w < wave; ++w) base += waveCount[w];
+        slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    } else if ((threadIdx.x & 63) == 0 && m) atomicAdd(pl.counters + (blockIdx.x % kAliveShards), (uint32_t)__popcll(m));
+    if (pl.compact ? need : valid) {
+        storeRay(wo.bsdfRays + slot, nr); wo.brec0[slot] = nrec; wo.refN[slot] = nrefN;
+        storeRay(wo.shadowRays + slot, sr); wo.lrec[slot] = nl;
+        wo.sampleIdx[slot] = i;
+    }
 }
 
 /* ---- filtered splat of the G samples a lane group holds of one pixel (ImageBlock::put, reduced across the group) -----------------------
@@ -741,8 +764,9 @@ void launchShade(hipStream_t st, const DScene &sc, const BatchParams &bp, const 
     hipLaunchKernelGGL(kShade, dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, wb);
 }
 
-void launchPathBounce(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb, uint32_t *alive) {
-    hipLaunchKernelGGL(kPathBounce, dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, wb, alive);
+void launchPathBounce(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &in, const WaveBuffers &out, const PathLaunch &pl) {
+    if (pl.nIn == 0) return;
+    hipLaunchKernelGGL(kPathBounce, dim3(blocksFor(pl.nIn, 256)), dim3(256), 0, st, sc, bp, in, out, pl);
 }
 
 void launchDevelop(hipStream_t st, const float *film, uint64_t n, int fmt, float *out) {
