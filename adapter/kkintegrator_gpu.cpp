@@ -133,6 +133,7 @@ public:
         ks.crop_offset_x = film->getCropOffset().x; ks.crop_offset_y = film->getCropOffset().y;
         ks.crop_width = film->getCropSize().x; ks.crop_height = film->getCropSize().y;
         ks.film_has_alpha = film->hasAlpha() ? 1 : 0;
+        ks.film_high_quality_edges = film->hasHighQualityEdges() ? 1 : 0;
         const ReconstructionFilter *rf = film->getReconstructionFilter();
         const std::string rfName = rf->getProperties().getPluginName();
         ks.rfilter_type = rfName == "box" ? KKD_RFILTER_BOX : rfName == "tent" ? KKD_RFILTER_TENT : rfName == "mitchell" ? KKD_RFILTER_MITCHELL

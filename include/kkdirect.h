@@ -138,6 +138,9 @@ typedef struct kkd_sensor {
     int32_t  rfilter_type;     /* KKD_RFILTER_*                                                */
     float    rfilter_radius;   /* gaussian: 4*stddev (=2); box: 0.5(+1e-5); tent 1; mitchell/catmullrom 2; lanczos: lobes */
     float    rfilter_param[2]; /* gaussian: stddev,-; mitchell: B,C; lanczos: lobes,-          */
+    int32_t  film_high_quality_edges; /* Film::hasHighQualityEdges(): the sampled area grows by the filter border on every side
+                                         (librender/film.cpp:54, librender/renderproc.cpp:166-171)  */
+    int32_t  reserved;
 } kkd_sensor;
 
 typedef struct kkd_scene_desc {

@@ -76,7 +76,8 @@ int ora_li_samples(ora_ctx *c, const kkd_render_params *p, uint64_t seed, const 
     const int W = c->scene.sensor.cropW;
     for (uint64_t i = 0; i < n; ++i) {
         uint32_t X = pix[3 * i], Y = pix[3 * i + 1], s = pix[3 * i + 2];
-        SampleStream rng(seed, Y * (uint32_t)W + X, s);
+        const int edge = c->scene.hqEdges ? c->scene.filter.borderSize : 0;   /* same pixel key as Scene::render */
+        SampleStream rng(seed, (uint32_t)(((int)Y + edge) * (W + 2 * edge) + ((int)X + edge)), s);
         V2 jit = rng.next2D();
         V2 sp{ (Float)X + jit.x, (Float)Y + jit.y };
         Ray ray = c->scene.sensor.sampleRay(sp);

@@ -354,7 +354,7 @@ public:
     std::vector<V3> tangU, tangV; std::vector<uint8_t> hasTang;   /* TriMesh::computeUVTangents */
     BSDFSet bsdfs; std::vector<EmitterRec> emitters; DiscreteDistribution emitterPDF;
     EnvMap env; int envEmitter = -1;
-    Sensor sensor; RFilter filter; bool filmHasAlpha = false;
+    Sensor sensor; RFilter filter; bool filmHasAlpha = false, hqEdges = false;
     KDTree kd; bool useBruteForce = false;
 
     bool load(const kkd_scene_desc *sd, std::string &err);
@@ -738,11 +738,13 @@ inline V3 Scene::LiPath(const Ray &r, SampleStream &rng, const RenderParams &rp,
  * with border and merged under a lock (renderproc.cpp:142-149). */
 inline void Scene::render(const RenderParams &rp, float *film, Stats *st, int nThreads) const {
     const int W = sensor.cropW, H = sensor.cropH, bs = rp.blockSize ? (int)rp.blockSize : 32;
-    const int nbx = (W + bs - 1) / bs, nby = (H + bs - 1) / bs, nTiles = nbx * nby;
+    const int border = filter.borderSize;
+    /* Film::hasHighQualityEdges: the image process covers offset (-border, -border), size + 2 border (renderproc.cpp:163-171) */
+    const int edge = hqEdges ? border : 0, EW = W + 2 * edge, EH = H + 2 * edge;
+    const int nbx = (EW + bs - 1) / bs, nby = (EH + bs - 1) / bs, nTiles = nbx * nby;
     std::memset(film, 0, sizeof(float) * 5 * (size_t)W * H);
     std::atomic<int> next{0};
     std::mutex filmMutex;
-    const int border = filter.borderSize;
     auto worker = [&]() {
         const int bw = bs + 2 * border;
         std::vector<float> block((size_t)bw * bw * 5);
@@ -751,14 +753,14 @@ inline void Scene::render(const RenderParams &rp, float *film, Stats *st, int nT
             int t = next.fetch_add(1);
             if (t >= nTiles) break;
             if (rp.tileCount > 1 && (uint32_t)t % rp.tileCount != rp.tileIndex) continue;
-            const int ox = (t % nbx) * bs, oy = (t / nbx) * bs;
-            const int sx = std::min(bs, W - ox), sy = std::min(bs, H - oy);
+            const int ox = (t % nbx) * bs - edge, oy = (t / nbx) * bs - edge;
+            const int sx = std::min(bs, W + edge - ox), sy = std::min(bs, H + edge - oy);
             const int sizeX = sx + 2 * border, sizeY = sy + 2 * border;
             std::fill(block.begin(), block.end(), 0.f);
             for (int py = 0; py < sy; ++py) for (int px = 0; px < sx; ++px) {
                 const int X = ox + px, Y = oy + py;
                 for (uint32_t j = 0; j < rp.spp; ++j) {
-                    SampleStream rng(rp.seed, (uint32_t)(Y * W + X), rp.sampleFirst + j);
+                    SampleStream rng(rp.seed, (uint32_t)((Y + edge) * EW + (X + edge)), rp.sampleFirst + j);
                     V2 jit = rng.next2D();
                     V2 samplePos{ (Float)X + jit.x, (Float)Y + jit.y };
                     Ray ray = sensor.sampleRay(samplePos);
@@ -894,7 +896,7 @@ inline bool Scene::load(const kkd_scene_desc *sd, std::string &err) {
         env.configure();
     }
     sensor.configure(sd->sensor);
-    filmHasAlpha = sd->sensor.film_has_alpha != 0;
+    filmHasAlpha = sd->sensor.film_has_alpha != 0; hqEdges = sd->sensor.film_high_quality_edges != 0;
     filter.configure(sd->sensor.rfilter_type, sd->sensor.rfilter_radius, sd->sensor.rfilter_param);
     if (filter.borderSize > 6) { err = "filter radius too large"; return false; }
     kd.build(mesh, shapeOfPrim, firstPrimOfShape);

@@ -350,7 +350,8 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     ctx->cancel.store(0);
 
     const int W = ctx->ds.sensor.cropW, H = ctx->ds.sensor.cropH;
-    const uint32_t nbx = (W + bs - 1) / bs, nby = (H + bs - 1) / bs, nTiles = nbx * nby;
+    const int edge = ctx->ds.sensor.hqEdges ? ctx->ds.filter.border : 0;   /* Film::hasHighQualityEdges (renderproc.cpp:163-171) */
+    const uint32_t nbx = (W + 2 * edge + bs - 1) / bs, nby = (H + 2 * edge + bs - 1) / bs, nTiles = nbx * nby;
     const uint32_t nTilesMine = tileIndex < nTiles ? (nTiles - tileIndex + tileCount - 1) / tileCount : 0;
     const uint32_t g = std::min(64u, pow2ceil(rp->spp)), chunks = (rp->spp + g - 1) / g;
     uint32_t gShift = 0; while ((1u << gShift) < g) ++gShift;
@@ -431,6 +432,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     bp.chunksShift = 32; bp.pixShift = 32;
     if ((chunks & (chunks - 1)) == 0) { bp.chunksShift = 0; while ((1u << bp.chunksShift) < chunks) ++bp.chunksShift; }
     if ((bs & (bs - 1)) == 0) { bp.pixShift = 0; while ((1u << bp.pixShift) < bs * bs) ++bp.pixShift; }
+    bp.edge = edge;
     bp.bs = bs; bp.bsPow2 = (bs & (bs - 1)) == 0; bp.nbx = nbx; bp.nby = nby;
     bp.tileIndex = tileIndex; bp.tileCount = tileCount; bp.nTilesMine = nTilesMine; bp.W = W; bp.H = H;
     { const char *dbg = getenv("KKD_DEBUG"); bp.debug = dbg ? (uint32_t)atoi(dbg) : 0u; }

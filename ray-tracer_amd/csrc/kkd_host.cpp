@@ -475,7 +475,7 @@ bool flattenScene(const kkd_scene_desc *sd, HostScene &hs, std::string &err, int
         for (int i = 0; i < 12; ++i) hs.sensor.toWorld[i] = s.to_world[i];
         hs.sensor.nearClip = s.near_clip; hs.sensor.farClip = s.far_clip;
         hs.sensor.invResX = 1.0f / (float)s.crop_width; hs.sensor.invResY = 1.0f / (float)s.crop_height;
-        hs.sensor.cropW = (int)s.crop_width; hs.sensor.cropH = (int)s.crop_height; hs.sensor.filmHasAlpha = s.film_has_alpha != 0; hs.sensor.pad = 0;
+        hs.sensor.cropW = (int)s.crop_width; hs.sensor.cropH = (int)s.crop_height; hs.sensor.filmHasAlpha = s.film_has_alpha != 0; hs.sensor.hqEdges = s.film_high_quality_edges != 0;
         if (s.rfilter_type < 0 || s.rfilter_type > KKD_RFILTER_LANCZOS) KKD_FAIL(KKD_ERR_INVALID, "unknown reconstruction filter");
         if (!(s.rfilter_radius > 0.f)) KKD_FAIL(KKD_ERR_INVALID, "filter radius must be positive");
         configureFilter(s.rfilter_type, s.rfilter_radius, s.rfilter_param, hs.filter);

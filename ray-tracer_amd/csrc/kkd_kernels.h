@@ -28,6 +28,7 @@ struct BatchParams {
     uint32_t depth;                       /* path plugin: depth of the vertex a kPathBounce launch shades (2, 3, ...) */
     uint32_t bs, bsPow2, nbx, nby, tileIndex, tileCount, nTilesMine;
     int32_t W, H;
+    int32_t edge;                    /* Film::hasHighQualityEdges: filter border by which the sampled area grows on every side, else 0 */
     uint32_t debug;                  /* developer ablation bits from $KKD_DEBUG: 1 = no film atomics, 2 = no BSDF-hit evaluation, 4 = no block-level film reduction, 64 = per-lane primary walk */
 };
 

@@ -51,10 +51,10 @@ __device__ __forceinline__ SampleId mapWorkItem(const BatchParams &bp, uint32_t 
     uint32_t px, py;
     if (bp.bsPow2) { px = compact1by1(pin); py = compact1by1(pin >> 1); }
     else { px = pin % bp.bs; py = pin / bp.bs; }
-    s.X = (int)(tx * bp.bs + px); s.Y = (int)(ty * bp.bs + py);
+    s.X = (int)(tx * bp.bs + px) - bp.edge; s.Y = (int)(ty * bp.bs + py) - bp.edge;   /* tiles start at (-edge, -edge), renderproc.cpp:163-171 */
     s.sample = chunk * bp.g + j;
-    s.active = i < bp.count && tileLocal < bp.nTilesMine && s.X < bp.W && s.Y < bp.H && s.sample < bp.spp;
-    s.pixel = (uint32_t)(s.Y * bp.W + s.X);
+    s.active = i < bp.count && tileLocal < bp.nTilesMine && s.X < bp.W + bp.edge && s.Y < bp.H + bp.edge && s.sample < bp.spp;
+    s.pixel = (uint32_t)((s.Y + bp.edge) * (bp.W + 2 * bp.edge) + (s.X + bp.edge));
     s.sample += bp.sampleFirst;
     return s;
 }
@@ -226,7 +226,10 @@ __device__ __forceinline__ void storeRay(DRay *dst, const DRay &r) {
     p[0] = make_float4(r.ox, r.oy, r.oz, r.mint); p[1] = make_float4(r.dx, r.dy, r.dz, r.maxt);
 }
 
-__global__ void __launch_bounds__(256, 4) kShade(DScene sc, BatchParams bp, WaveBuffers wb) {
+#ifndef KKD_SHADE_WAVES
+#define KKD_SHADE_WAVES 4      /* blocks of 256 per CU = waves per SIMD */
+#endif
+__global__ void __launch_bounds__(256, KKD_SHADE_WAVES) kShade(DScene sc, BatchParams bp, WaveBuffers wb) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= bp.count) return;
     const SampleId s = mapWorkItem(bp, i);

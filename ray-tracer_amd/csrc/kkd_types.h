@@ -107,7 +107,7 @@ struct DSensor {
     float toWorld[12];         /* rows of the affine camera-to-world matrix                   */
     float s2c[16];             /* sampleToCamera, full projective 4x4                         */
     float nearClip, farClip, invResX, invResY;
-    int32_t cropW, cropH, filmHasAlpha, pad;
+    int32_t cropW, cropH, filmHasAlpha, hqEdges;
 };
 
 struct DFilter { float values[32]; float radius, scaleFactor; int32_t border, pad; };

@@ -54,7 +54,7 @@ class Sensor(C.Structure):
     _fields_ = [("to_world", f32 * 16), ("xfov_deg", f32), ("near_clip", f32), ("far_clip", f32),
                 ("film_width", u32), ("film_height", u32), ("crop_offset_x", u32), ("crop_offset_y", u32),
                 ("crop_width", u32), ("crop_height", u32), ("film_has_alpha", i32), ("rfilter_type", i32),
-                ("rfilter_radius", f32), ("rfilter_param", f32 * 2)]
+                ("rfilter_radius", f32), ("rfilter_param", f32 * 2), ("film_high_quality_edges", i32), ("reserved", i32)]
 
 
 class SceneDesc(C.Structure):

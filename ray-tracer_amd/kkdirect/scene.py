@@ -169,7 +169,7 @@ class Scene:
         return len(self.emitters) - 1
 
     def set_sensor(self, to_world, xfov_deg, width, height, near=1e-2, far=1e4, crop=None, has_alpha=False,
-                   rfilter=abi.RFILTER_GAUSSIAN, rfilter_radius=None, rfilter_param=None):
+                   rfilter=abi.RFILTER_GAUSSIAN, rfilter_radius=None, rfilter_param=None, high_quality_edges=False):
         s = abi.Sensor()
         tw = np.asarray(to_world, np.float32).reshape(16)
         for i in range(16):
@@ -179,6 +179,7 @@ class Scene:
         cx, cy, cw, ch = crop if crop else (0, 0, width, height)
         s.crop_offset_x, s.crop_offset_y, s.crop_width, s.crop_height = cx, cy, cw, ch
         s.film_has_alpha = int(has_alpha)
+        s.film_high_quality_edges = int(high_quality_edges)
         s.rfilter_type = rfilter
         defaults = {abi.RFILTER_GAUSSIAN: (2.0, (0.5, 0.0)), abi.RFILTER_BOX: (0.5 + 1e-5, (0.0, 0.0)),
                     abi.RFILTER_TENT: (1.0, (0.0, 0.0)), abi.RFILTER_MITCHELL: (2.0, (1 / 3.0, 1 / 3.0)),

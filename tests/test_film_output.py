@@ -88,3 +88,40 @@ def test_develop_device_on_rendered_film(gpu, tmp_path):
             ctx.develop(host, 17)
     kkdirect.write_pfm(str(tmp_path / "cbox.pfm"), out)
     assert (tmp_path / "cbox.pfm").read_bytes() == kkoracle.pfm_bytes(out)
+
+
+# ---- Film 'highQualityEdges' (librender/film.cpp:54; BlockedRenderProcess::bindResource, librender/renderproc.cpp:163-171) ----
+def _hq_scene(hq, w=40, h=24):
+    from kkdirect import scenes, look_at
+    sc = scenes.cornell_box(w, h)
+    sc.set_sensor(look_at((278, 273, -800), (278, 273, -799), (0, 1, 0)), 39.3077, w, h, near=10.0, far=2800.0, high_quality_edges=hq)
+    return sc
+
+
+def test_high_quality_edges_oracle_samples_the_border():
+    import kkoracle
+    w, h, spp, b = 40, 24, 8, 2                      # default Gaussian: border 2
+    plain, sp = kkoracle.Oracle(_hq_scene(False)).render(spp)
+    hq, sh = kkoracle.Oracle(_hq_scene(True)).render(spp)
+    assert sp.samples == w * h * spp and sh.samples == (w + 2 * b) * (h + 2 * b) * spp
+    # the samples taken outside the film only add filter weight near the edges: interior weights agree in expectation,
+    # edge pixels gain weight, and the film keeps its size
+    assert hq.shape == plain.shape
+    interior = plain[6:-6, 6:-6, 4].mean()
+    for edge_plain, edge_hq in ((plain[0, :, 4], hq[0, :, 4]), (plain[:, 0, 4], hq[:, 0, 4]), (plain[-1, :, 4], hq[-1, :, 4]), (plain[:, -1, 4], hq[:, -1, 4])):
+        assert edge_plain.mean() < 0.9 * interior            # half of the footprints that would reach an edge pixel are missing
+        assert abs(edge_hq.mean() / interior - 1) < 0.06     # with the border sampled, edge pixels weigh like interior ones
+    assert abs(hq[6:-6, 6:-6, 4].mean() / plain[6:-6, 6:-6, 4].mean() - 1) < 0.05
+
+
+@pytest.mark.gpu
+def test_high_quality_edges_gpu_matches_oracle():
+    import kkoracle, kkdirect, helpers
+    for blk in (0, 16):
+        sc = _hq_scene(True)
+        ref, so = kkoracle.Oracle(sc).render(32, seed=1, block_size=blk)
+        with kkdirect.Context(device=0, seed=1).upload(sc) as ctx:
+            film, sg = ctx.render(32, block_size=blk)
+        assert sg.samples == so.samples == 44 * 28 * 32
+        np.testing.assert_allclose(film[..., 4], ref[..., 4], rtol=1e-4, atol=1e-4)
+        assert helpers.rel_mse(helpers.develop(film), helpers.develop(ref)) < 1e-5
