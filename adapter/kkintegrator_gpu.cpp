@@ -159,6 +159,10 @@ public:
         if (!m_ctx) Log(EError, "kkIntegrator: %s", kkd_last_error(NULL));          /* throws (src/librender/renderjob.cpp:111-115) */
         if (kkd_scene_upload(m_ctx, &sd) != KKD_OK) { std::string msg = kkd_last_error(m_ctx); kkd_destroy(m_ctx); m_ctx = NULL; Log(EError, "kkIntegrator: %s", msg.c_str()); }
 
+        /* progress: ProgressReporter as BlockedRenderProcess does (src/librender/renderproc.cpp:146, 179) */
+        ProgressReporter progress("Rendering", 1000, job);
+        kkd_set_progress_callback(m_ctx, &DirectIntegratorGPU::onProgress, &progress);
+
         kkd_render_params rp; memset(&rp, 0, sizeof(rp));
         rp.spp = (uint32_t) scene->getSampler()->getSampleCount();                   /* src/librender/integrator.cpp:103-104 */
         rp.bsdf_samples = (uint32_t) m_bsdfSamples; rp.light_samples = (uint32_t) m_lightSamples; rp.hide_emitters = m_hideEmitters;
@@ -178,6 +182,10 @@ public:
         }
         kkd_destroy(m_ctx); m_ctx = NULL;
         return rc == KKD_OK;                                                         /* false on cancel (src/librender/integrator.cpp:128) */
+    }
+
+    static void onProgress(void *user, uint64_t done, uint64_t total) {
+        static_cast<ProgressReporter *>(user)->update((size_t) (total ? done * 1000 / total : 1000));
     }
 
     void cancel() { if (m_ctx) kkd_request_cancel(m_ctx); DirectIntegrator::cancel(); }   /* src/librender/integrator.cpp:90-93 */

@@ -389,6 +389,15 @@ void kkd_mesh_free(kkd_mesh *mesh);
 /* Asynchronous, thread-safe: replaces SamplingIntegrator::cancel (src/librender/integrator.cpp:90-93). */
 void kkd_request_cancel(kkd_ctx *ctx);
 
+/* Progress of a render: replaces ProgressReporter::update per finished block (BlockedRenderProcess::processResult,
+ * src/librender/renderproc.cpp:142-149) and gives the adapter its hook for RenderQueue::signalWorkEnd / signalRefresh
+ * (src/librender/renderqueue.cpp:119-141).  fn is called on the thread inside kkd_render / kkd_render_device, between
+ * batches, with the number of work items (camera samples, including the padding of partial tiles) whose results are in
+ * the film (completed on the device) and their total;
+ * the last call of a finished render reports done == total.  fn == NULL removes the callback.  It must not call into ctx. */
+typedef void (*kkd_progress_fn)(void *user, uint64_t samples_done, uint64_t samples_total);
+int kkd_set_progress_callback(kkd_ctx *ctx, kkd_progress_fn fn, void *user);
+
 /* Mitsuba convention is Log(EError, ...) -> exception (src/librender/renderjob.cpp:111-115); here the
  * text is kept per context.  Never NULL.  ctx == NULL returns the last error of kkd_create. */
 const char *kkd_last_error(kkd_ctx *ctx);

@@ -57,6 +57,8 @@ struct kkd_ctx {
     int capClosest = 28, capAny = 20;
     DevBuf hits, accum, refN, bsdfRays, bsdfHits, brec0, shadowRays, occluded, lrec, film, counters, apiRays, apiHits;
     std::vector<hipEvent_t> events;
+    std::vector<hipEvent_t> doneEvents;   /* one per batch in flight: recorded after the batch's splat (progress reports) */
+    kkd_progress_fn progressFn = nullptr; void *progressUser = nullptr;
 };
 
 #define KKD_HIP(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
@@ -114,6 +116,12 @@ const char *kkd_last_error(kkd_ctx *ctx) { return ctx ? ctx->err.c_str() : g_glo
 
 void kkd_request_cancel(kkd_ctx *ctx) { if (ctx) ctx->cancel.store(1); }
 
+int kkd_set_progress_callback(kkd_ctx *ctx, kkd_progress_fn fn, void *user) {
+    if (!ctx) return KKD_ERR_INVALID;
+    ctx->progressFn = fn; ctx->progressUser = user;
+    return KKD_OK;
+}
+
 void kkd_destroy(kkd_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
@@ -126,6 +134,7 @@ void kkd_destroy(kkd_ctx *ctx) {
                       &ctx->pathAlive, &ctx->pBsdfRays, &ctx->pBrec, &ctx->pRefN, &ctx->pShadowRays, &ctx->pLrec, &ctx->pSampleIdx };
     for (DevBuf *b : all) b->release();
     for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
+    for (hipEvent_t ev : ctx->doneEvents) hipEventDestroy(ev);
     for (hipStream_t s : ctx->laneStreams) if (s) hipStreamDestroy(s);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -457,8 +466,32 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     uint64_t launches[5] = { 0, 0, 0, 0, 0 };
     bool cancelled = false;
     uint64_t batchIndex = 0;
+    /* progress: a ring of "batch done" events (a lane runs its batches in order, so at most a few are outstanding);
+     * completed ones are polled between batches, never waited for */
+    constexpr size_t kDoneRing = 16;
+    const bool report = ctx->progressFn != nullptr;
+    while (report && ctx->doneEvents.size() < kDoneRing) { hipEvent_t e; KKD_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->doneEvents.push_back(e); }
+    uint64_t doneCount[kDoneRing] = {}; bool donePending[kDoneRing] = {};
+    uint64_t finishedSamples = 0;
+    auto pollProgress = [&](bool wait) {
+        if (!report) return;
+        uint64_t add = 0;
+        for (size_t k = 0; k < kDoneRing; ++k) {
+            if (!donePending[k]) continue;
+            if (wait) hipEventSynchronize(ctx->doneEvents[k]);
+            if (hipEventQuery(ctx->doneEvents[k]) == hipSuccess) { donePending[k] = false; add += doneCount[k]; }
+        }
+        if (add) { finishedSamples += add; ctx->progressFn(ctx->progressUser, std::min(finishedSamples, total), total); }
+    };
+    auto batchDone = [&](hipStream_t st, uint64_t index, uint64_t count) {      /* after the batch's splat has been queued */
+        if (!report) return;
+        const size_t k = (size_t)(index % kDoneRing);
+        if (donePending[k]) { hipEventSynchronize(ctx->doneEvents[k]); pollProgress(false); }
+        hipEventRecord(ctx->doneEvents[k], st); doneCount[k] = count; donePending[k] = true;
+    };
     for (uint64_t w0 = 0; w0 < total; w0 += batch, ++batchIndex) {
         if (ctx->cancel.load()) { cancelled = true; break; }
+        pollProgress(false);
         const int lane = (int)(batchIndex % (uint64_t)nLanes);
         const hipStream_t st = laneStream[lane];
         const WaveBuffers &wb = wbL[lane]; const TraceContinuation &cont = contL[lane];
@@ -522,6 +555,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
                 /* never compacted: slot j still holds sample j, so kResolve adds the last segments itself, as for the direct plugin */
                 bp.depth = 1;
                 launchResolve(st, ctx->ds, bp, wb, film, ctr); launches[KKD_STAGE_RESOLVE]++;
+                batchDone(st, batchIndex, bp.count);
                 continue;
             }
             /* what the last segments found goes into the per-sample sums; kResolve then only splats them */
@@ -531,10 +565,12 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
             bp.depth = 1;
             BatchParams bpSplat = bp; bpSplat.nB = 0; bpSplat.nL = 0;
             launchResolve(st, ctx->ds, bpSplat, wb, film, ctr); launches[KKD_STAGE_RESOLVE]++;
+            batchDone(st, batchIndex, bp.count);
             continue;
         }
         if (timeStages) hipEventRecord(ctx->events[ev++], st);
         launchResolve(st, ctx->ds, bp, wb, film, ctr); launches[KKD_STAGE_RESOLVE]++;
+        batchDone(st, batchIndex, bp.count);
         if (timeStages) hipEventRecord(ctx->events[ev++], st);
     }
     KKD_HIP(ctx, hipGetLastError());
@@ -546,6 +582,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     std::vector<DeviceCounters> shards(kCounterShards);
     KKD_HIP(ctx, hipMemcpyAsync(shards.data(), ctr, kCounterShards * sizeof(DeviceCounters), hipMemcpyDeviceToHost, st0));
     KKD_HIP(ctx, hipStreamSynchronize(st0));
+    pollProgress(true);
     const DeviceCounters c = sumShards(shards);
     {
         /* Budget control over the whole render: too many parked rays and the second round repeats their set-up for

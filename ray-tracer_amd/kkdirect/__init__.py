@@ -95,6 +95,11 @@ class Context:
         return abi.RenderParams(spp, bsdf_samples, light_samples, int(hide_emitters), block_size, tile_index, tile_count, sample_first,
                                 integrator, int(strict_normals), max_depth, rr_depth)
 
+    def set_progress_callback(self, fn):
+        """fn(samples_done, samples_total) is called between batches of a render (kkd_set_progress_callback); None removes it."""
+        self._progress = abi.PROGRESS_FN(lambda user, done, total: fn(done, total)) if fn else abi.PROGRESS_FN()
+        self._check(self.lib.kkd_set_progress_callback(self.h, self._progress, None))
+
     def render(self, spp, bsdf_samples=1, light_samples=1, hide_emitters=False, block_size=0, tile_index=0, tile_count=1,
                sample_first=0, integrator=abi.INTEGRATOR_KK, strict_normals=False, max_depth=-1, rr_depth=5):
         """-> (film[H, W, 5] float32 = {R*w, G*w, B*w, alpha*w, w}, abi.Stats)"""

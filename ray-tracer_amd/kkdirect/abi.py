@@ -70,6 +70,9 @@ class Config(C.Structure):
     _fields_ = [("device", i32), ("flags", u32), ("seed", u64), ("max_samples_in_flight", u64)]
 
 
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64)
+
+
 class RenderParams(C.Structure):
     _fields_ = [("spp", u32), ("bsdf_samples", u32), ("light_samples", u32), ("hide_emitters", i32),
                 ("block_size", u32), ("tile_index", u32), ("tile_count", u32), ("sample_first", u32),
@@ -122,6 +125,7 @@ ENTRY_POINTS = {
     "kkd_mesh_load_ply": (C.c_int, [C.c_char_p, pf32, i32, C.POINTER(Mesh)]),
     "kkd_mesh_free": (None, [C.POINTER(Mesh)]),
     "kkd_request_cancel": (None, [C.c_void_p]),
+    "kkd_set_progress_callback": (C.c_int, [C.c_void_p, PROGRESS_FN, C.c_void_p]),
     "kkd_last_error": (C.c_char_p, [C.c_void_p]),
     "kkd_destroy": (None, [C.c_void_p]),
 }

@@ -95,3 +95,24 @@ def test_two_batch_lanes_equal_one_lane():
         assert stats[1].stage_launches[0] >= 2          # more than one batch, so the second lane was used
         np.testing.assert_allclose(films[0], films[1], rtol=2e-4, atol=1e-4)
         assert np.isfinite(films[1]).all()
+
+
+@pytest.mark.gpu
+def test_progress_callback_reports_finished_batches():
+    """kkd_set_progress_callback: called between batches with the samples whose results are in the film, monotonically, and
+    with done == total at the end (the adapter's hook for ProgressReporter / RenderQueue::signalWorkEnd)."""
+    import kkdirect
+    from kkdirect import scenes
+    sc = scenes.cornell_box(128, 128)
+    with kkdirect.Context(device=0, seed=1, max_samples_in_flight=65536).upload(sc) as ctx:
+        calls = []
+        ctx.set_progress_callback(lambda done, total: calls.append((done, total)))
+        film, st = ctx.render(32)                     # 524 288 samples: 8 batches
+        assert len(calls) >= 2 and all(t == calls[0][1] for _, t in calls)
+        dones = [d for d, _ in calls]
+        assert dones == sorted(dones) and len(set(dones)) == len(dones)
+        assert dones[-1] == calls[-1][1] >= st.samples
+        n = len(calls)
+        ctx.set_progress_callback(None)
+        ctx.render(8)
+        assert len(calls) == n
