@@ -197,6 +197,11 @@ def main():
                     "one_lane_ms_per_step": round(one_lane_ms, 3),
                     "algorithmic_bytes_per_launch": round(bytes_k[dom] / max(1, stage_n[dom])),
                     "nodes_per_ray": [round(p[0], 2) for p in per_ray], "tris_per_ray": [round(p[1], 2) for p in per_ray],
+                    # whole job: algorithmic bytes of all five stages per second of the timed region, and the
+                    # compulsory lower bound (scene structures read once + film written once) the re-reads are measured against
+                    "job_algorithmic_gbps": round(sum(sum(stage_bytes(s_, n_b, n_l, per_ray, acc["node_bytes"], acc["tri_bytes"])) for s_ in stats) / elapsed / 1e9, 2),
+                    "compulsory_bytes_per_step": int(acc["n_nodes"] * (acc["node_bytes"] + 128) + acc["n_leaf_tris"] * acc["tri_bytes"]
+                                                     + scene._nv * (12 + 12 + 8) + scene._nt * 12 + W * H * 5 * 4),
                     "stage_ms_per_step": {abi.STAGE_NAMES[k]: round(stage_s[k] / args.steps * 1e3, 3) for k in range(5)},
                     "stage_ms_per_step_timed_region": {abi.STAGE_NAMES[k]: round(shared_s[k] / args.steps * 1e3, 3) for k in range(5)}}
         cpu = None
