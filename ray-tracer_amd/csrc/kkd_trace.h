@@ -199,6 +199,8 @@ struct Walk {
                 } else {
     #define KKD_CSWAP(DA, CA, DB, CB) { const bool s = DB < DA; const float td = s ? DB : DA; DB = s ? DA : DB; DA = td; \
                                         const uint32_t tc = s ? CB : CA; CB = s ? CA : CB; CA = tc; }
+                /* (sorting only as far as the nearest child -- 3 or 4 of the 5 comparators -- was measured: C2 BSDF rays 71.3 -> 73.7 /
+                 * 72.8 ms, C4 166 -> 163 / 164 ms: the full order is kept) */
                 KKD_CSWAP(d0, c0, d1, c1) KKD_CSWAP(d2, c2, d3, c3) KKD_CSWAP(d0, c0, d2, c2) KKD_CSWAP(d1, c1, d3, c3) KKD_CSWAP(d1, c1, d2, c2)
     #undef KKD_CSWAP
                 if (d0 < kInf) {

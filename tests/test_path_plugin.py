@@ -60,7 +60,7 @@ PATH_CASES = [dict(max_depth=1), dict(max_depth=2), dict(max_depth=3), dict(max_
 @pytest.mark.parametrize("kw", PATH_CASES)
 def test_gpu_path_matches_oracle_same_stream(kw):
     """Same sample stream, so GPU and oracle walk the same paths and the images agree to rounding.  Exception, measured
-    (scripts/diag_path.py): paths of more than ~30 vertices exist only inside the glass sphere of the all-materials scene
+    (tests/tools/diag_path.py): paths of more than ~30 vertices exist only inside the glass sphere of the all-materials scene
     (total internal reflection), where every bounce off the curved surface doubles a rounding difference, so those few paths
     (160 of 405 000 BSDF rays) end up elsewhere: up to depth 30 relMSE is 3e-6, unbounded 7e-4 with equal means.  The
     unbounded cases therefore get a looser image bound on that scene plus a bound on the mean."""

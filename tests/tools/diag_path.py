@@ -1,5 +1,5 @@
 import os, sys
-ROOT = "/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "ray-tracer_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 import numpy as np, kkdirect, kkoracle, helpers
 from kkdirect import abi, scenes

@@ -1,6 +1,6 @@
 """Ad-hoc first GPU run: hit-ID parity + Cornell image parity vs the oracle."""
 import sys, os, time, numpy as np
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, 'oracle')); sys.path.insert(0, os.path.join(R, 'ray-tracer_amd'))
 import kkoracle, kkdirect
 from kkdirect import scenes

@@ -1,6 +1,6 @@
 """Print the same-sample-stream image parity numbers quoted in DESIGN.md / README.md (GPU vs oracle)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "ray-tracer_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 import numpy as np, kkdirect, kkoracle, helpers
 from kkdirect import scenes

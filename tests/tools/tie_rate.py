@@ -1,7 +1,7 @@
 """Tie rate of hit ids (GPU vs oracle Wald test) on the full C2 scene, camera + secondary rays.
    argv[1] = "proj": GPU leaf test = KKD_FLAG_PROJECTION_TEST instead of the watertight test."""
 import sys, os, time, numpy as np
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, 'oracle')); sys.path.insert(0, os.path.join(R, 'ray-tracer_amd')); sys.path.insert(0, os.path.join(R, 'tests'))
 import kkoracle, kkdirect, helpers
 from kkdirect import scenes
