@@ -229,8 +229,11 @@ typedef struct kkd_stats {
     uint64_t class_rays[3];    /* rays actually traced per class (KKD_RAYS_*)                   */
     uint64_t class_nodes[3];   /* BVH nodes visited per class   (only with KKD_FLAG_COUNT_TRAVERSAL) */
     uint64_t class_tris[3];    /* triangles tested per class    (only with KKD_FLAG_COUNT_TRAVERSAL) */
-    double   stage_seconds[5]; /* device time per kernel stage (KKD_STAGE_*), summed over launches */
-    uint64_t stage_launches[5];
+    double   stage_seconds[5]; /* device time per kernel stage (KKD_STAGE_*), summed over launches.  A render keeps two batches
+                                  in flight on two streams, so a stage's time includes the other batch's kernels sharing the GPU
+                                  and the five add up to more than `seconds`; with KKD_FLAG_ONE_LANE they are exclusive.  Zero
+                                  for KKD_INTEGRATOR_PATH (a batch is a loop of stages there; only `seconds` is timed) */
+    uint64_t stage_launches[5];/* kernel launches per stage */
 } kkd_stats;
 
 typedef struct kkd_hit {       /* IntersectionCache of skdtree.h: {shapeIndex, primIndex, u, v} + t */
