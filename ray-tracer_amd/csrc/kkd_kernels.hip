@@ -77,22 +77,36 @@ __device__ __forceinline__ void countTraversal(uint32_t nn, uint32_t nt, DeviceC
     if ((threadIdx.x & 63) == 0) { atomicAdd(&ctr->nodes[cls], (unsigned long long)nn); atomicAdd(&ctr->tris[cls], (unsigned long long)nt); }
 }
 
+#ifndef KKD_PRIMARY_RAYS
+#define KKD_PRIMARY_RAYS 2     /* rays per lane of the packet walk of the primary rays: the walk is bound by its scalar side, which is
+                                  paid per wave -- measured on C2: 1: 28.7 ms, 2: 21.3 ms, 3: 22.0 ms, 4: 21.8 ms per frame */
+#endif
 template <bool COUNT, bool PROJ, bool PACKET, int STACK, int BLOCK>
-__global__ void __launch_bounds__(BLOCK, 8) kPrimary(DScene sc, BatchParams bp, DHit *__restrict__ hits, DeviceCounters *ctr) {
+__global__ void __launch_bounds__(BLOCK, !PACKET || KKD_PRIMARY_RAYS == 1 ? 8 : (KKD_PRIMARY_RAYS == 2 ? 5 : 3)) kPrimary(DScene sc, BatchParams bp, DHit *__restrict__ hits, DeviceCounters *ctr) {
     /* PACKET: one wave-uniform stack per wave; else one stack per lane */
     __shared__ uint32_t sstack[PACKET ? (BLOCK / 64) * kMaxTraversalStack : STACK * BLOCK];
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    const SampleId s = mapWorkItem(bp, i);
-    DRay ray; ray.maxt = -1.f; ray.mint = 0.f; ray.ox = ray.oy = ray.oz = 0.f; ray.dx = ray.dy = 0.f; ray.dz = 1.f;
-    float sx, sy;
-    if (s.active) ray = primaryRay(sc, bp, s, sx, sy);
+    constexpr int R = PACKET ? KKD_PRIMARY_RAYS : 1;
+    /* a wave takes R * 64 consecutive work items: lane l the items base + l (+ 64): R lane groups of one pixel when spp allows */
+    const uint32_t base = (blockIdx.x * BLOCK + (threadIdx.x & ~63u)) * R + (threadIdx.x & 63u);
+    DRay ray[R]; DHit h[R]; bool active[R];
     uint32_t nn = 0, nt = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const SampleId s = mapWorkItem(bp, base + 64u * r);
+        ray[r].maxt = -1.f; ray[r].mint = 0.f; ray[r].ox = ray[r].oy = ray[r].oz = 0.f; ray[r].dx = ray[r].dy = 0.f; ray[r].dz = 1.f;
+        float sx, sy;
+        active[r] = s.active;
+        if (s.active) ray[r] = primaryRay(sc, bp, s, sx, sy);
+    }
     const void *triTable = PROJ ? (const void *)sc.projTris : (const void *)sc.tris;
-    const DHit h = PACKET ? traversePacket<COUNT, PROJ>(sc.wideNodes, triTable, ray, sstack + (threadIdx.x >> 6) * kMaxTraversalStack, nn, nt)
-                          : traverse<false, COUNT, PROJ, STACK, BLOCK>(sc.nodes, triTable, ray, sstack, nn, nt);
-    if (i < bp.count) hits[i] = h;
+    if (PACKET) traversePacket<COUNT, PROJ, R>(sc.wideNodes, triTable, ray, sstack + (threadIdx.x >> 6) * kMaxTraversalStack, h, nn, nt);
+    else h[0] = traverse<false, COUNT, PROJ, STACK, BLOCK>(sc.nodes, triTable, ray[0], sstack, nn, nt);
     ctr = counterShard(ctr);
-    countRays(s.active, &ctr->rays[KKD_RAYS_PRIMARY]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (base + 64u * r < bp.count) hits[base + 64u * r] = h[r];
+        countRays(active[r], &ctr->rays[KKD_RAYS_PRIMARY]);
+    }
     if (COUNT) countTraversal(nn, nt, ctr, KKD_RAYS_PRIMARY);
 }
 
@@ -728,8 +742,8 @@ __global__ void __launch_bounds__(256) kDevelop(const float *__restrict__ film, 
 static inline uint32_t blocksFor(uint64_t n, uint32_t block) { return (uint32_t)((n + block - 1) / block); }
 
 void launchPrimary(hipStream_t st, bool count, const DScene &sc, const BatchParams &bp, DHit *hits, DeviceCounters *ctr) {
-    const dim3 grid(blocksFor(bp.count, 256)), block(256);
-    const bool packet = !(bp.debug & 64u);     /* $KKD_DEBUG bit 64: per-lane walk for primary rays (A/B measurements) */
+    const bool packet = !(bp.debug & 64u);
+    const dim3 grid(blocksFor(bp.count, 256 * (packet ? KKD_PRIMARY_RAYS : 1))), block(256);     /* $KKD_DEBUG bit 64: per-lane walk for primary rays (A/B measurements) */
 #define KKD_LP(C, P, K) hipLaunchKernelGGL((kPrimary<C, P, K, kStackLds, 256>), grid, block, 0, st, sc, bp, hits, ctr)
     if (sc.projTris) {
         if (count) { if (packet) KKD_LP(true, true, true); else KKD_LP(true, true, false); }

@@ -265,10 +265,10 @@ __device__ __forceinline__ DHit traverse(const Node4 *__restrict__ nodes, const 
  * negative), 8 otherwise.  With a known octant the near and the far plane of every slab are known at compile time, so a
  * child costs 6 fma + 2 max/max3 + 2 min/min3 instead of 6 more min / max -- same values, same walk, a third fewer VALU
  * instructions in a kernel that is VALU-issue bound.  Primary rays of one pixel share their octant except across an axis. */
-template <bool COUNT, bool PROJ, int OCT>
-__device__ __forceinline__ void packetWalk(const WideNode *__restrict__ wnodes, const float4 *__restrict__ tris4, const DRay &ray, const WoopRay &wr,
-                                           float ox, float oy, float oz, float idx, float idy, float idz, float tmin, float &tmax,
-                                           uint32_t *wstack, DHit &hit, uint32_t &nNodes, uint32_t &nTris) {
+template <bool COUNT, bool PROJ, int OCT, int R>
+__device__ __forceinline__ void packetWalk(const WideNode *__restrict__ wnodes, const float4 *__restrict__ tris4, const DRay *ray, const WoopRay *wr,
+                                           const float *idx, const float *idy, const float *idz, const float *tmin, float *tmax,
+                                           uint32_t *wstack, DHit *hit, uint32_t &nNodes, uint32_t &nTris) {
     int sp = 0;
     uint32_t cur = 0;
     /* every wave leaves this loop: each iteration pops or descends in a finite tree; the step bound ends a malformed one */
@@ -278,30 +278,38 @@ __device__ __forceinline__ void packetWalk(const WideNode *__restrict__ wnodes, 
             /* (reading the record as eight 16-byte words up front instead was measured slower: 30.1 vs 28.9 ms; the scalar side
              * of this loop, ~85 SALU instructions per node visit, bounds it together with the VALU side) */
             const WideNode *n = wnodes + cur;
-            const float tbx = (n->ox - ox) * idx, tby = (n->oy - oy) * idy, tbz = (n->oz - oz) * idz;
+            float tbx[R], tby[R], tbz[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) { tbx[r] = (n->ox - ray[r].ox) * idx[r]; tby[r] = (n->oy - ray[r].oy) * idy[r]; tbz[r] = (n->oz - ray[r].oz) * idz[r]; }
             uint32_t dk[4], ck[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 ck[k] = n->child[k]; dk[k] = 0xFFFFFFFFu;
                 if (ck[k] == 0u) continue;         /* empty slot (wave-uniform) */
-                float tn, tf;
-                if (OCT < 8) {
-                    const float nx = (OCT & 1) ? n->rmaxx[k] : n->rminx[k], fx = (OCT & 1) ? n->rminx[k] : n->rmaxx[k];
-                    const float ny = (OCT & 2) ? n->rmaxy[k] : n->rminy[k], fy = (OCT & 2) ? n->rminy[k] : n->rmaxy[k];
-                    const float nz = (OCT & 4) ? n->rmaxz[k] : n->rminz[k], fz = (OCT & 4) ? n->rminz[k] : n->rmaxz[k];
-                    tn = fmaxf(fmaxf(fmaf(nx, idx, tbx), fmaf(ny, idy, tby)), fmaxf(fmaf(nz, idz, tbz), tmin));
-                    tf = fminf(fminf(fmaf(fx, idx, tbx), fmaf(fy, idy, tby)), fminf(fmaf(fz, idz, tbz), tmax));
-                } else {
-                    const float t0x = fmaf(n->rminx[k], idx, tbx), t1x = fmaf(n->rmaxx[k], idx, tbx);
-                    const float t0y = fmaf(n->rminy[k], idy, tby), t1y = fmaf(n->rmaxy[k], idy, tby);
-                    const float t0z = fmaf(n->rminz[k], idz, tbz), t1z = fmaf(n->rmaxz[k], idz, tbz);
-                    tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
-                    tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+                bool h = false; float tnMin = kInf;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float tn, tf;
+                    if (OCT < 8) {
+                        const float nx = (OCT & 1) ? n->rmaxx[k] : n->rminx[k], fx = (OCT & 1) ? n->rminx[k] : n->rmaxx[k];
+                        const float ny = (OCT & 2) ? n->rmaxy[k] : n->rminy[k], fy = (OCT & 2) ? n->rminy[k] : n->rmaxy[k];
+                        const float nz = (OCT & 4) ? n->rmaxz[k] : n->rminz[k], fz = (OCT & 4) ? n->rminz[k] : n->rmaxz[k];
+                        tn = fmaxf(fmaxf(fmaf(nx, idx[r], tbx[r]), fmaf(ny, idy[r], tby[r])), fmaxf(fmaf(nz, idz[r], tbz[r]), tmin[r]));
+                        tf = fminf(fminf(fmaf(fx, idx[r], tbx[r]), fmaf(fy, idy[r], tby[r])), fminf(fmaf(fz, idz[r], tbz[r]), tmax[r]));
+                    } else {
+                        const float t0x = fmaf(n->rminx[k], idx[r], tbx[r]), t1x = fmaf(n->rmaxx[k], idx[r], tbx[r]);
+                        const float t0y = fmaf(n->rminy[k], idy[r], tby[r]), t1y = fmaf(n->rmaxy[k], idy[r], tby[r]);
+                        const float t0z = fmaf(n->rminz[k], idz[r], tbz[r]), t1z = fmaf(n->rmaxz[k], idz[r], tbz[r]);
+                        tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin[r]));
+                        tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax[r]));
+                    }
+                    const bool hr = tn * 0.999999f <= tf * 1.000001f;
+                    if (COUNT && hr) { if (ck[k] & kLeafBit) nTris += ((ck[k] >> 28) & 7u) + 1u; else ++nNodes; }
+                    if (R == 1) { h = hr; tnMin = tn; }
+                    else { h = h || hr; tnMin = hr ? fminf(tnMin, tn) : tnMin; }
                 }
-                const bool h = tn * 0.999999f <= tf * 1.000001f;
                 const unsigned long long m = __ballot(h);
-                if (COUNT && h) { if (ck[k] & kLeafBit) nTris += ((ck[k] >> 28) & 7u) + 1u; else ++nNodes; }
-                if (m) dk[k] = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tn), __ffsll((long long)m) - 1);   /* tn >= 0: orders as uint */
+                if (m) dk[k] = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tnMin), __ffsll((long long)m) - 1);   /* tn >= 0: orders as uint */
             }
 #define KKD_SSWAP(A, B) { if (dk[B] < dk[A]) { const uint32_t td = dk[A]; dk[A] = dk[B]; dk[B] = td; const uint32_t tc = ck[A]; ck[A] = ck[B]; ck[B] = tc; } }
             KKD_SSWAP(0, 1) KKD_SSWAP(2, 3) KKD_SSWAP(0, 2) KKD_SSWAP(1, 3) KKD_SSWAP(1, 2)
@@ -315,10 +323,13 @@ __device__ __forceinline__ void packetWalk(const WideNode *__restrict__ wnodes, 
             for (uint32_t i = 0; i < cnt; ++i) {
                 const float4 *tp = tris4 + 3u * (start + i);
                 const float4 a = tp[0], b = tp[1], c = tp[2];
-                float t, u, v;
-                if (PROJ ? projIntersect(ox, oy, oz, ray.dx, ray.dy, ray.dz, a, b, c, tmin, tmax, t, u, v)
-                         : woopIntersect(wr, ox, oy, oz, a, b, c, tmin, tmax, t, u, v)) {
-                    tmax = t; hit.t = t; hit.u = u; hit.v = v; hit.id = start + i;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float t, u, v;
+                    if (PROJ ? projIntersect(ray[r].ox, ray[r].oy, ray[r].oz, ray[r].dx, ray[r].dy, ray[r].dz, a, b, c, tmin[r], tmax[r], t, u, v)
+                             : woopIntersect(wr[r], ray[r].ox, ray[r].oy, ray[r].oz, a, b, c, tmin[r], tmax[r], t, u, v)) {
+                        tmax[r] = t; hit[r].t = t; hit[r].u = u; hit[r].v = v; hit[r].id = start + i;
+                    }
                 }
             }
         }
@@ -327,35 +338,49 @@ __device__ __forceinline__ void packetWalk(const WideNode *__restrict__ wnodes, 
     }
 }
 
-template <bool COUNT, bool PROJ>
-__device__ __forceinline__ DHit traversePacket(const WideNode *__restrict__ wnodes, const void *__restrict__ tris, const DRay &ray,
-                                               uint32_t *wstack, uint32_t &nNodes, uint32_t &nTris) {
-    DHit hit; hit.t = kInf; hit.u = 0.f; hit.v = 0.f; hit.id = kNoHit;
-    const float ox = ray.ox, oy = ray.oy, oz = ray.oz;
-    const float tmin = adaptiveMinT<false>(ray.mint, ox, oy, oz);
-    float tmax = ray.maxt;
-    if (!(tmax > tmin)) tmax = -1.0f;              /* dead lane: no box and no triangle is ever hit */
-    const unsigned long long live = __ballot(tmax > tmin);
-    if (live == 0ull) return hit;
+/* R rays per lane (1 or 2): with two, a wave walks for 128 rays at once -- the scalar work of the walk (node fetches, ballots,
+ * sorting network, wave stack) is paid per wave, so it halves per ray. */
+template <bool COUNT, bool PROJ, int R>
+__device__ __forceinline__ void traversePacket(const WideNode *__restrict__ wnodes, const void *__restrict__ tris, const DRay *ray,
+                                               uint32_t *wstack, DHit *hit, uint32_t &nNodes, uint32_t &nTris) {
+    float tmin[R], tmax[R], idx[R], idy[R], idz[R];
+    WoopRay wr[R];
+    bool anyLive = false;
     const float kBig = 0x1p100f, kTiny = 0x1p-100f;
-    const float idx = fabsf(ray.dx) < kTiny ? copysignf(kBig, ray.dx) : 1.0f / ray.dx;
-    const float idy = fabsf(ray.dy) < kTiny ? copysignf(kBig, ray.dy) : 1.0f / ray.dy;
-    const float idz = fabsf(ray.dz) < kTiny ? copysignf(kBig, ray.dz) : 1.0f / ray.dz;
-    WoopRay wr; wr.init(ray.dx, ray.dy, ray.dz);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        hit[r].t = kInf; hit[r].u = 0.f; hit[r].v = 0.f; hit[r].id = kNoHit;
+        tmin[r] = adaptiveMinT<false>(ray[r].mint, ray[r].ox, ray[r].oy, ray[r].oz);
+        tmax[r] = ray[r].maxt;
+        if (!(tmax[r] > tmin[r])) tmax[r] = -1.0f;              /* dead ray: no box and no triangle is ever hit */
+        anyLive = anyLive || tmax[r] > tmin[r];
+    }
+    const unsigned long long liveLanes = __ballot(anyLive);
+    if (liveLanes == 0ull) return;
+    /* sign octant of the live rays (a dead ray hits nothing whatever planes it is given) */
+    unsigned long long mx = 0, my = 0, mz = 0, px = 0, py = 0, pz = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        idx[r] = fabsf(ray[r].dx) < kTiny ? copysignf(kBig, ray[r].dx) : 1.0f / ray[r].dx;
+        idy[r] = fabsf(ray[r].dy) < kTiny ? copysignf(kBig, ray[r].dy) : 1.0f / ray[r].dy;
+        idz[r] = fabsf(ray[r].dz) < kTiny ? copysignf(kBig, ray[r].dz) : 1.0f / ray[r].dz;
+        wr[r].init(ray[r].dx, ray[r].dy, ray[r].dz);
+        const bool live = tmax[r] > tmin[r];
+        mx |= __ballot(live && idx[r] < 0.f); px |= __ballot(live && !(idx[r] < 0.f));
+        my |= __ballot(live && idy[r] < 0.f); py |= __ballot(live && !(idy[r] < 0.f));
+        mz |= __ballot(live && idz[r] < 0.f); pz |= __ballot(live && !(idz[r] < 0.f));
+    }
     const float4 *tris4 = reinterpret_cast<const float4 *>(tris);
-    if (COUNT) ++nNodes;                           /* the root */
-    /* sign octant of the live lanes (a dead lane hits nothing whatever planes it is given) */
-    const unsigned long long mx = __ballot(idx < 0.f) & live, my = __ballot(idy < 0.f) & live, mz = __ballot(idz < 0.f) & live;
-    const bool uniform = (mx == 0ull || mx == live) && (my == 0ull || my == live) && (mz == 0ull || mz == live);
+    if (COUNT) nNodes += (uint32_t)R;              /* the root */
+    const bool uniform = (mx == 0ull || px == 0ull) && (my == 0ull || py == 0ull) && (mz == 0ull || pz == 0ull);
     const int oct = uniform ? ((mx ? 1 : 0) | (my ? 2 : 0) | (mz ? 4 : 0)) : 8;
-#define KKD_PW(O) packetWalk<COUNT, PROJ, O>(wnodes, tris4, ray, wr, ox, oy, oz, idx, idy, idz, tmin, tmax, wstack, hit, nNodes, nTris)
+#define KKD_PW(O) packetWalk<COUNT, PROJ, O, R>(wnodes, tris4, ray, wr, idx, idy, idz, tmin, tmax, wstack, hit, nNodes, nTris)
     switch (oct) {
         case 0: KKD_PW(0); break; case 1: KKD_PW(1); break; case 2: KKD_PW(2); break; case 3: KKD_PW(3); break;
         case 4: KKD_PW(4); break; case 5: KKD_PW(5); break; case 6: KKD_PW(6); break; case 7: KKD_PW(7); break;
         default: KKD_PW(8); break;
     }
 #undef KKD_PW
-    return hit;
 }
 
 } /* namespace kkd */
