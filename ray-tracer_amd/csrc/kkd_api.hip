@@ -50,7 +50,7 @@ struct kkd_ctx {
     DScene ds{};
     /* scene buffers */
     DevBuf nodes, wideNodes, tris, projTris, positions, normals, texcoords, indices, shapes, materials, emitters, emitterCdf, areaCdf, rtTables,
-           envTexels, envCdfRows, envCdfCols, envRowWeights;
+           envTexels, envCdfRows, envCdfCols, envRowWeights, envGuideRows, envGuideCols;
     /* work buffers */
     DevBuf contRecs, contStacks, contCount, pathAlive, pBsdfRays, pBrec, pRefN, pShadowRays, pLrec, pSampleIdx;
     /* first-round step budgets of the round-based traversal; adapted from the share of rays the last batch parked */
@@ -131,7 +131,7 @@ void kkd_destroy(kkd_ctx *ctx) {
                       &ctx->emitters, &ctx->emitterCdf, &ctx->areaCdf, &ctx->rtTables, &ctx->envTexels, &ctx->envCdfRows, &ctx->envCdfCols,
                       &ctx->envRowWeights, &ctx->contRecs, &ctx->contStacks, &ctx->contCount, &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->shadowRays,
                       &ctx->occluded, &ctx->lrec, &ctx->film, &ctx->counters, &ctx->apiRays, &ctx->apiHits,
-                      &ctx->pathAlive, &ctx->pBsdfRays, &ctx->pBrec, &ctx->pRefN, &ctx->pShadowRays, &ctx->pLrec, &ctx->pSampleIdx };
+                      &ctx->envGuideRows, &ctx->envGuideCols, &ctx->pathAlive, &ctx->pBsdfRays, &ctx->pBrec, &ctx->pRefN, &ctx->pShadowRays, &ctx->pLrec, &ctx->pSampleIdx };
     for (DevBuf *b : all) b->release();
     for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->doneEvents) hipEventDestroy(ev);
@@ -173,6 +173,8 @@ int kkd_scene_upload(kkd_ctx *ctx, const kkd_scene_desc *sd) {
     UP(envCdfRows, hs.envCdfRows.data(), hs.envCdfRows.size())
     UP(envCdfCols, hs.envCdfCols.data(), hs.envCdfCols.size())
     UP(envRowWeights, hs.envRowWeights.data(), hs.envRowWeights.size())
+    UP(envGuideRows, hs.envGuideRows.data(), hs.envGuideRows.size())
+    UP(envGuideCols, hs.envGuideCols.data(), hs.envGuideCols.size())
 #undef UP
     KKD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     DScene &d = ctx->ds;
@@ -188,6 +190,7 @@ int kkd_scene_upload(kkd_ctx *ctx, const kkd_scene_desc *sd) {
     d.env = hs.env;
     d.env.texels = (const uint32_t *)ctx->envTexels.p; d.env.cdfRows = (const float *)ctx->envCdfRows.p;
     d.env.cdfCols = (const float *)ctx->envCdfCols.p; d.env.rowWeights = (const float *)ctx->envRowWeights.p;
+    d.env.guideRows = (const uint32_t *)ctx->envGuideRows.p; d.env.guideCols = (const uint32_t *)ctx->envGuideCols.p;
     d.sensor = hs.sensor; d.filter = hs.filter;
     /* host copies that are only needed for the upload */
     std::vector<uint16_t>().swap(hs.envTexels); std::vector<float>().swap(hs.envCdfCols);

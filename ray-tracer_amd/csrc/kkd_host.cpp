@@ -443,6 +443,16 @@ bool flattenScene(const kkd_scene_desc *sd, HostScene &hs, std::string &err, int
         const float norm = 1.0f / rowSum;
         for (int y = 1; y < h; ++y) hs.envCdfRows[rowPos - y - 1] *= norm;
         hs.envCdfRows[rowPos - 1] = 1.0f;
+        {   /* guide tables (kkd_types.h): lower_bound of the bucket boundaries, rows and every row's columns */
+            auto guide = [](const float *cdf, size_t n, uint32_t G, uint32_t *out) {
+                for (uint32_t b = 0; b <= G; ++b) out[b] = (uint32_t)(std::lower_bound(cdf, cdf + n, (float)b / (float)G) - cdf);
+                out[G] = std::min<uint32_t>(out[G], (uint32_t)n - 1);   /* cdf[n - 1] = 1 >= every sample */
+            };
+            hs.envGuideRows.resize(kEnvGuideRows + 1);
+            guide(hs.envCdfRows.data(), (size_t)h + 1, kEnvGuideRows, hs.envGuideRows.data());
+            hs.envGuideCols.resize((size_t)h * (kEnvGuideCols + 1));
+            for (int y = 0; y < h; ++y) guide(hs.envCdfCols.data() + (size_t)y * (w + 1), (size_t)w + 1, kEnvGuideCols, hs.envGuideCols.data() + (size_t)y * (kEnvGuideCols + 1));
+        }
         hs.env.normalization = 1.0f / (rowSum * (2 * kPi / w) * (kPi / h));
         hs.env.pixelSizeX = 2 * kPi / w; hs.env.pixelSizeY = kPi / h;
         for (int i = 0; i < 9; ++i) hs.env.toWorld[i] = k.to_world[i];

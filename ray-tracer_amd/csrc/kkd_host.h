@@ -28,6 +28,7 @@ struct HostScene {
     DEnvMap env{};                   /* pointer members filled after upload */
     std::vector<uint16_t> envTexels; /* RGBA half */
     std::vector<float> envCdfRows, envCdfCols, envRowWeights;
+    std::vector<uint32_t> envGuideRows, envGuideCols;
     DSensor sensor{};
     DFilter filter{};
     uint64_t nVerts = 0, nTris = 0;

@@ -110,8 +110,10 @@ __device__ __forceinline__ uint32_t cdfSampleReuse(const float *cdf, uint32_t n,
     return index;
 }
 /* envmap.cpp:653-658 */
-__device__ __forceinline__ uint32_t envSampleReuse(const float *cdf, uint32_t size, float &sample) {
-    uint32_t lo = 0, cnt = size + 1;
+__device__ __forceinline__ uint32_t envSampleReuse(const float *cdf, uint32_t size, float &sample, const uint32_t *guide, uint32_t G) {
+    /* std::lower_bound over the size + 1 entries, started on the bracket the guide table gives for the sample's bucket */
+    const uint32_t b = min((uint32_t)(sample * (float)G), G - 1u);
+    uint32_t lo = guide[b], cnt = guide[b + 1u] - lo + 1u;
     while (cnt > 0) {
         const uint32_t step = cnt >> 1, mid = lo + step;
         if (cdf[mid] < sample) { lo = mid + 1; cnt -= step + 1; } else cnt = step;
@@ -161,8 +163,8 @@ __device__ __forceinline__ float envPdfDirection(const DEnvMap &e, f3 d) {
 }
 /* envmap.cpp:567-600 */
 __device__ __forceinline__ void envSampleDirection(const DEnvMap &e, f2 sample, f3 &d, f3 &value, float &pdf) {
-    const uint32_t row = envSampleReuse(e.cdfRows, (uint32_t)e.h, sample.y);
-    const uint32_t col = envSampleReuse(e.cdfCols + (size_t)row * (e.w + 1), (uint32_t)e.w, sample.x);
+    const uint32_t row = envSampleReuse(e.cdfRows, (uint32_t)e.h, sample.y, e.guideRows, kEnvGuideRows);
+    const uint32_t col = envSampleReuse(e.cdfCols + (size_t)row * (e.w + 1), (uint32_t)e.w, sample.x, e.guideCols + row * (kEnvGuideCols + 1u), kEnvGuideCols);
     const float px = (float)col + intervalToTent(sample.x), py = (float)row + intervalToTent(sample.y);
     f3 a, b; int yPos;
     envBilinearRows(e, px, py, a, b, yPos);

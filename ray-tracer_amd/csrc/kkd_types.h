@@ -101,7 +101,12 @@ struct DEnvMap {
     const float *cdfRows;      /* h+1                                                        */
     const float *cdfCols;      /* (w+1)*h                                                    */
     const float *rowWeights;   /* h                                                          */
+    /* guide tables of the two CDF searches: entry b = lower_bound(cdf, b / G), so the first entry >= a sample in bucket b lies
+     * in [guide[b], guide[b + 1]] and the binary search starts on that bracket (same result, 3-6 dependent loads, not 11-12) */
+    const uint32_t *guideRows; /* kEnvGuideRows + 1                                          */
+    const uint32_t *guideCols; /* h * (kEnvGuideCols + 1)                                    */
 };
+static constexpr uint32_t kEnvGuideRows = 256, kEnvGuideCols = 64;   /* powers of two: sample * G is exact */
 
 struct DSensor {
     float toWorld[12];         /* rows of the affine camera-to-world matrix                   */
