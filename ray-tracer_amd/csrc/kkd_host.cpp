@@ -402,6 +402,12 @@ bool flattenScene(const kkd_scene_desc *sd, HostScene &hs, std::string &err, int
         for (size_t j = 1; j < hs.emitterCdf.size(); ++j) hs.emitterCdf[j] *= hs.emitterNormalization;
         hs.emitterCdf.back() = 1.0f;
     }
+    {   /* guide table of the emitter CDF search (kkd_types.h) */
+        const size_t n = hs.emitterCdf.size();
+        hs.emitterGuide.resize(kEmitterGuide + 1);
+        for (uint32_t b = 0; b <= kEmitterGuide; ++b)
+            hs.emitterGuide[b] = std::min<uint32_t>((uint32_t)(std::lower_bound(hs.emitterCdf.begin(), hs.emitterCdf.end(), (float)b / (float)kEmitterGuide) - hs.emitterCdf.begin()), (uint32_t)n - 1);
+    }
 
     /* environment map (envmap.cpp:260-329) */
     std::memset(&hs.env, 0, sizeof(hs.env));

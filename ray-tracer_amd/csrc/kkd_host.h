@@ -22,6 +22,7 @@ struct HostScene {
     std::vector<DMaterial> materials;
     std::vector<DEmitter> emitters;
     std::vector<float> emitterCdf, areaCdf, rtTables;
+    std::vector<uint32_t> emitterGuide;
     int envEmitter = -1;
     float emitterNormalization = 0.f;
     /* envmap */

@@ -91,8 +91,13 @@ __device__ __forceinline__ void fillIntersection(const DScene &sc, f3 rayD, cons
 }
 
 /* pmf.h DiscreteDistribution::sample: lower_bound over n+1 entries, skip zero-probability entries */
-__device__ __forceinline__ uint32_t cdfSample(const float *cdf, uint32_t n, float v) {
+template <bool GUIDED = false>
+__device__ __forceinline__ uint32_t cdfSample(const float *cdf, uint32_t n, float v, const uint32_t *guide = nullptr) {
     uint32_t lo = 0, cnt = n + 1;
+    if (GUIDED) {   /* bracket of the sample's bucket (kkd_types.h): same lower_bound, ~4 instead of ~14 dependent loads for 10 k emitters */
+        const uint32_t b = min((uint32_t)(v * (float)kEmitterGuide), kEmitterGuide - 1u);
+        lo = guide[b]; cnt = guide[b + 1u] - lo + 1u;
+    }
     while (cnt > 0) {
         const uint32_t step = cnt >> 1, mid = lo + step;
         if (cdf[mid] < v) { lo = mid + 1; cnt -= step + 1; } else cnt = step;
@@ -102,8 +107,9 @@ __device__ __forceinline__ uint32_t cdfSample(const float *cdf, uint32_t n, floa
     while (index + 1 < n && cdf[index + 1] - cdf[index] == 0.f) ++index;
     return index;
 }
-__device__ __forceinline__ uint32_t cdfSampleReuse(const float *cdf, uint32_t n, float &v, float &pdf) {
-    const uint32_t index = cdfSample(cdf, n, v);
+template <bool GUIDED = false>
+__device__ __forceinline__ uint32_t cdfSampleReuse(const float *cdf, uint32_t n, float &v, float &pdf, const uint32_t *guide = nullptr) {
+    const uint32_t index = cdfSample<GUIDED>(cdf, n, v, guide);
     const float c0 = cdf[index], c1 = cdf[index + 1];
     pdf = c1 - c0;
     v = fdiv(v - c0, c1 - c0);
@@ -187,7 +193,7 @@ __device__ __forceinline__ f3 areaEval(const DEmitter &e, f3 shN, f3 d) {
  * returns value = Le / pdf with pdf including the emitter-selection probability; zero if not sampleable. */
 __device__ __forceinline__ f3 sampleEmitterDirectUnoccluded(const DScene &sc, DirectRec &dRec, f2 sample) {
     float emPdf;
-    const uint32_t index = cdfSampleReuse(sc.emitterCdf, sc.nEmitters, sample.x, emPdf);
+    const uint32_t index = cdfSampleReuse<true>(sc.emitterCdf, sc.nEmitters, sample.x, emPdf, sc.emitterGuide);
     const DEmitter e = sc.emitters[index];
     f3 value(0.f);
     dRec.pdf = 0.f;

@@ -106,6 +106,7 @@ struct DEnvMap {
     const uint32_t *guideRows; /* kEnvGuideRows + 1                                          */
     const uint32_t *guideCols; /* h * (kEnvGuideCols + 1)                                    */
 };
+static constexpr uint32_t kEmitterGuide = 1024;
 static constexpr uint32_t kEnvGuideRows = 256, kEnvGuideCols = 64;   /* powers of two: sample * G is exact */
 
 struct DSensor {
@@ -124,6 +125,7 @@ struct DScene {
     const float *positions; const float *normals; const float *texcoords; const uint32_t *indices;
     const DShape *shapes; const DMaterial *materials; const DEmitter *emitters;
     const float *emitterCdf;   /* nEmitters+1                                                 */
+    const uint32_t *emitterGuide; /* kEmitterGuide + 1 entries: lower_bound(emitterCdf, b / kEmitterGuide), brackets the search */
     const float *areaCdf;      /* concatenated per-emitter-shape triangle area CDFs            */
     const float *rtTables;     /* rough-transmittance tables, 100 floats each                  */
     uint32_t nShapes, nMaterials, nEmitters; int32_t envEmitter;
