@@ -165,8 +165,9 @@ struct Walk {
                 float d0, d1, d2, d3;
                 /* Slab test in the node's grid: t(plane q) = (origin + q * scale - o) / d = q * ta + tb, so a plane costs one
                  * byte->float conversion and one fma.  The near / far plane of each axis is picked by the sign of the ray
-                 * direction for all four children at once (one select of the packed byte quadruple).  The 1e-6 slack on
-                 * both sides covers the rounding of ta, tb (the builder's enclosure check covers the grid itself). */
+                 * direction for all four children at once (one select of the packed byte quadruple).  The 2e-6 slack on the
+                 * far side covers the rounding of ta, tb (the builder's enclosure check covers the grid itself; one multiply
+                 * instead of one on each side: tn >= 0 on this path). */
                 const float tax = sx * idx, tay = sy * idy, taz = sz * idz;
                 const float tbx = (gx - ox) * idx, tby = (gy - oy) * idy, tbz = (gz - oz) * idz;
                 const uint32_t nx4 = negx ? qa.w : qa.x, fx4 = negx ? qa.x : qa.w;
@@ -178,7 +179,7 @@ struct Walk {
                 const float tnz = fmaf((float)((nz4 >> (8 * K)) & 0xffu), taz, tbz), tfz = fmaf((float)((fz4 >> (8 * K)) & 0xffu), taz, tbz); \
                 const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin)); \
                 const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tmax)); \
-                D = (tn * 0.999999f <= tf * 1.000001f && (C) != 0u) ? tn : kInf; }
+                D = (tn <= tf * 1.000002f && (C) != 0u) ? tn : kInf; }
                 KKD_SLAB(d0, 0, ch.x)
                 KKD_SLAB(d1, 1, ch.y)
                 KKD_SLAB(d2, 2, ch.z)
@@ -303,7 +304,7 @@ __device__ __forceinline__ void packetWalk(const WideNode *__restrict__ wnodes, 
                         tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin[r]));
                         tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax[r]));
                     }
-                    const bool hr = tn * 0.999999f <= tf * 1.000001f;
+                    const bool hr = tn <= tf * 1.000002f;
                     if (COUNT && hr) { if (ck[k] & kLeafBit) nTris += ((ck[k] >> 28) & 7u) + 1u; else ++nNodes; }
                     if (R == 1) { h = hr; tnMin = tn; }
                     else { h = h || hr; tnMin = hr ? fminf(tnMin, tn) : tnMin; }
