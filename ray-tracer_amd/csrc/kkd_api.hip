@@ -49,7 +49,7 @@ struct kkd_ctx {
     HostScene hs;
     DScene ds{};
     /* scene buffers */
-    DevBuf nodes, wideNodes, tris, projTris, positions, normals, texcoords, indices, shapes, materials, emitters, emitterCdf, emitterGuide, areaCdf, rtTables,
+    DevBuf nodes, wideNodes, tris, projTris, positions, normals, texcoords, indices, shapes, materials, emitters, emitterCdf, emitterGuide, areaGuide, areaCdf, rtTables,
            envTexels, envCdfRows, envCdfCols, envRowWeights, envGuideRows, envGuideCols;
     /* work buffers */
     DevBuf contRecs, contStacks, contCount, pathAlive, pBsdfRays, pBrec, pRefN, pShadowRays, pLrec, pSampleIdx;
@@ -131,7 +131,7 @@ void kkd_destroy(kkd_ctx *ctx) {
                       &ctx->emitters, &ctx->emitterCdf, &ctx->areaCdf, &ctx->rtTables, &ctx->envTexels, &ctx->envCdfRows, &ctx->envCdfCols,
                       &ctx->envRowWeights, &ctx->contRecs, &ctx->contStacks, &ctx->contCount, &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->shadowRays,
                       &ctx->occluded, &ctx->lrec, &ctx->film, &ctx->counters, &ctx->apiRays, &ctx->apiHits,
-                      &ctx->envGuideRows, &ctx->envGuideCols, &ctx->emitterGuide, &ctx->pathAlive, &ctx->pBsdfRays, &ctx->pBrec, &ctx->pRefN, &ctx->pShadowRays, &ctx->pLrec, &ctx->pSampleIdx };
+                      &ctx->envGuideRows, &ctx->envGuideCols, &ctx->emitterGuide, &ctx->areaGuide, &ctx->pathAlive, &ctx->pBsdfRays, &ctx->pBrec, &ctx->pRefN, &ctx->pShadowRays, &ctx->pLrec, &ctx->pSampleIdx };
     for (DevBuf *b : all) b->release();
     for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->doneEvents) hipEventDestroy(ev);
@@ -168,6 +168,7 @@ int kkd_scene_upload(kkd_ctx *ctx, const kkd_scene_desc *sd) {
     UP(emitters, hs.emitters.data(), hs.emitters.size())
     UP(emitterCdf, hs.emitterCdf.data(), hs.emitterCdf.size())
     UP(emitterGuide, hs.emitterGuide.data(), hs.emitterGuide.size())
+    UP(areaGuide, hs.areaGuide.data(), hs.areaGuide.size())
     UP(areaCdf, hs.areaCdf.data(), hs.areaCdf.size())
     UP(rtTables, hs.rtTables.data(), hs.rtTables.size())
     UP(envTexels, hs.envTexels.data(), hs.envTexels.size())
@@ -185,7 +186,7 @@ int kkd_scene_upload(kkd_ctx *ctx, const kkd_scene_desc *sd) {
     d.positions = (const float *)ctx->positions.p; d.normals = (const float *)ctx->normals.p; d.texcoords = (const float *)ctx->texcoords.p;
     d.indices = (const uint32_t *)ctx->indices.p;
     d.shapes = (const DShape *)ctx->shapes.p; d.materials = (const DMaterial *)ctx->materials.p; d.emitters = (const DEmitter *)ctx->emitters.p;
-    d.emitterGuide = (const uint32_t *)ctx->emitterGuide.p;
+    d.emitterGuide = (const uint32_t *)ctx->emitterGuide.p; d.areaGuide = (const uint32_t *)ctx->areaGuide.p;
     d.emitterCdf = (const float *)ctx->emitterCdf.p; d.areaCdf = (const float *)ctx->areaCdf.p; d.rtTables = (const float *)ctx->rtTables.p;
     d.nShapes = (uint32_t)hs.shapes.size(); d.nMaterials = (uint32_t)hs.materials.size(); d.nEmitters = (uint32_t)hs.emitters.size();
     d.envEmitter = hs.envEmitter; d.emitterNormalization = hs.emitterNormalization;

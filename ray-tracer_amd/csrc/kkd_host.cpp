@@ -354,6 +354,8 @@ bool flattenScene(const kkd_scene_desc *sd, HostScene &hs, std::string &err, int
     /* emitters, scene emitter PDF, area CDFs */
     hs.emitters.resize(sd->n_emitters); hs.emitterCdf.assign(1, 0.0f); hs.areaCdf.clear(); hs.envEmitter = -1;
     std::vector<int64_t> shapeCdf(sd->n_shapes, -1); std::vector<float> shapeInvArea(sd->n_shapes, 0.f);
+    std::vector<uint32_t> shapeGuide(sd->n_shapes, 0u);
+    hs.areaGuide.assign(1, 0u);
     for (uint32_t i = 0; i < sd->n_emitters; ++i) {
         const kkd_emitter &k = sd->emitters[i]; DEmitter &e = hs.emitters[i];
         std::memset(&e, 0, sizeof(e));
@@ -380,8 +382,14 @@ bool flattenScene(const kkd_scene_desc *sd, HostScene &hs, std::string &err, int
                 for (size_t j = base + 1; j < hs.areaCdf.size(); ++j) hs.areaCdf[j] *= norm;
                 hs.areaCdf.back() = 1.0f;
                 shapeInvArea[e.shape] = 1.0f / sum;
+                if (s.nPrims >= kAreaGuideMinPrims) {   /* guide table of this CDF's search (kkd_types.h) */
+                    shapeGuide[e.shape] = (uint32_t)hs.areaGuide.size() + 1u;
+                    const float *cdf = hs.areaCdf.data() + base; const size_t n = (size_t)s.nPrims + 1;
+                    for (uint32_t b = 0; b <= kAreaGuide; ++b)
+                        hs.areaGuide.push_back(std::min<uint32_t>((uint32_t)(std::lower_bound(cdf, cdf + n, (float)b / (float)kAreaGuide) - cdf), (uint32_t)n - 1));
+                }
             }
-            e.cdfOffset = (uint32_t)shapeCdf[e.shape]; e.invArea = shapeInvArea[e.shape];
+            e.cdfOffset = (uint32_t)shapeCdf[e.shape]; e.invArea = shapeInvArea[e.shape]; e.guideOffset = shapeGuide[e.shape];
             e.firstPrim = s.firstPrim; e.nPrims = s.nPrims; e.shapeFlags = s.flags;
         } else if (e.type == KKD_EMITTER_POINT) {
             e.shape = -1;

@@ -22,7 +22,7 @@ struct HostScene {
     std::vector<DMaterial> materials;
     std::vector<DEmitter> emitters;
     std::vector<float> emitterCdf, areaCdf, rtTables;
-    std::vector<uint32_t> emitterGuide;
+    std::vector<uint32_t> emitterGuide, areaGuide;
     int envEmitter = -1;
     float emitterNormalization = 0.f;
     /* envmap */

@@ -91,11 +91,11 @@ __device__ __forceinline__ void fillIntersection(const DScene &sc, f3 rayD, cons
 }
 
 /* pmf.h DiscreteDistribution::sample: lower_bound over n+1 entries, skip zero-probability entries */
-template <bool GUIDED = false>
+template <uint32_t G = 0>
 __device__ __forceinline__ uint32_t cdfSample(const float *cdf, uint32_t n, float v, const uint32_t *guide = nullptr) {
     uint32_t lo = 0, cnt = n + 1;
-    if (GUIDED) {   /* bracket of the sample's bucket (kkd_types.h): same lower_bound, ~4 instead of ~14 dependent loads for 10 k emitters */
-        const uint32_t b = min((uint32_t)(v * (float)kEmitterGuide), kEmitterGuide - 1u);
+    if (G != 0u && guide) {   /* bracket of the sample's bucket (kkd_types.h): same lower_bound, ~4 instead of ~14 dependent loads for 10 k entries */
+        const uint32_t b = min((uint32_t)(v * (float)G), G - 1u);
         lo = guide[b]; cnt = guide[b + 1u] - lo + 1u;
     }
     while (cnt > 0) {
@@ -107,9 +107,9 @@ __device__ __forceinline__ uint32_t cdfSample(const float *cdf, uint32_t n, floa
     while (index + 1 < n && cdf[index + 1] - cdf[index] == 0.f) ++index;
     return index;
 }
-template <bool GUIDED = false>
+template <uint32_t G = 0>
 __device__ __forceinline__ uint32_t cdfSampleReuse(const float *cdf, uint32_t n, float &v, float &pdf, const uint32_t *guide = nullptr) {
-    const uint32_t index = cdfSample<GUIDED>(cdf, n, v, guide);
+    const uint32_t index = cdfSample<G>(cdf, n, v, guide);
     const float c0 = cdf[index], c1 = cdf[index + 1];
     pdf = c1 - c0;
     v = fdiv(v - c0, c1 - c0);
@@ -193,13 +193,14 @@ __device__ __forceinline__ f3 areaEval(const DEmitter &e, f3 shN, f3 d) {
  * returns value = Le / pdf with pdf including the emitter-selection probability; zero if not sampleable. */
 __device__ __forceinline__ f3 sampleEmitterDirectUnoccluded(const DScene &sc, DirectRec &dRec, f2 sample) {
     float emPdf;
-    const uint32_t index = cdfSampleReuse<true>(sc.emitterCdf, sc.nEmitters, sample.x, emPdf, sc.emitterGuide);
+    const uint32_t index = cdfSampleReuse<kEmitterGuide>(sc.emitterCdf, sc.nEmitters, sample.x, emPdf, sc.emitterGuide);
     const DEmitter e = sc.emitters[index];
     f3 value(0.f);
     dRec.pdf = 0.f;
     if (e.type == KKD_EMITTER_AREA) {
         float dummy;
-        const uint32_t local = cdfSampleReuse(sc.areaCdf + e.cdfOffset, e.nPrims, sample.y, dummy);
+        const uint32_t local = cdfSampleReuse<kAreaGuide>(sc.areaCdf + e.cdfOffset, e.nPrims, sample.y, dummy,
+                                                             e.guideOffset ? sc.areaGuide + (e.guideOffset - 1u) : nullptr);
         const uint32_t prim = e.firstPrim + local;
         const uint32_t *ip = sc.indices + 3u * prim;
         const uint32_t i0 = ip[0], i1 = ip[1], i2 = ip[2];

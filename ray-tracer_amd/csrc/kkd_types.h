@@ -89,7 +89,10 @@ struct DEmitter {           /* 64 bytes */
     int32_t type, shape; float weight, invArea;
     float radiance[3]; uint32_t cdfOffset;     /* area: offset of the shape's (nPrims+1)-entry area CDF in areaCdf */
     float position[3]; uint32_t firstPrim;
-    uint32_t nPrims, shapeFlags, pad[2];
+    uint32_t nPrims, shapeFlags;
+    uint32_t guideOffset;      /* area emitters on meshes of >= kAreaGuideMinPrims triangles: 1 + offset of the kAreaGuide + 1 guide
+                                  entries of the area CDF in areaGuide; 0 = none */
+    uint32_t pad;
 };
 
 struct DEnvMap {
@@ -106,7 +109,7 @@ struct DEnvMap {
     const uint32_t *guideRows; /* kEnvGuideRows + 1                                          */
     const uint32_t *guideCols; /* h * (kEnvGuideCols + 1)                                    */
 };
-static constexpr uint32_t kEmitterGuide = 1024;
+static constexpr uint32_t kEmitterGuide = 1024, kAreaGuide = 256, kAreaGuideMinPrims = 64;
 static constexpr uint32_t kEnvGuideRows = 256, kEnvGuideCols = 64;   /* powers of two: sample * G is exact */
 
 struct DSensor {
@@ -125,6 +128,7 @@ struct DScene {
     const float *positions; const float *normals; const float *texcoords; const uint32_t *indices;
     const DShape *shapes; const DMaterial *materials; const DEmitter *emitters;
     const float *emitterCdf;   /* nEmitters+1                                                 */
+    const uint32_t *areaGuide;    /* guide tables of the area CDFs of large emissive meshes (DEmitter::guideOffset) */
     const uint32_t *emitterGuide; /* kEmitterGuide + 1 entries: lower_bound(emitterCdf, b / kEmitterGuide), brackets the search */
     const float *areaCdf;      /* concatenated per-emitter-shape triangle area CDFs            */
     const float *rtTables;     /* rough-transmittance tables, 100 floats each                  */
