@@ -1,33 +1,51 @@
 /*
- * adapter/kkintegrator_gpu.cpp -- the Mitsuba-side half of the drop-in.
+ * adapter/kkintegrator_gpu.h -- the Mitsuba-side half of the drop-in.
  *
  * NOT COMPILED IN THIS REPOSITORY: it needs a Mitsuba 0.5 header tree (<mitsuba/render/scene.h> ...), which neither the
  * reference checkout (src/ only) nor the build image holds.  Everything it calls on the library side is built and tested
- * here (include/kkdirect.h; the parameter extraction it relies on is kkd_parse_bsdf_stream, tests/test_adapter_params.py).
- * Build against a Mitsuba tree:  add this file to the 'kkIntegrator' target next to integrators/kk/direct.cpp
- * (src/integrators/SConscript:44), -I<repo>/include, link -lkkdirect.
+ * here (include/kkdirect.h; the parameter extraction it relies on is kkd_parse_bsdf_stream, tests/test_adapter_params.py),
+ * and tests/test_adapter_params.py checks every Mitsuba-side name it uses against the reference's sources.
  *
- * What it does: keeps the plugin name, parameters and serialisation of DirectIntegrator (src/integrators/kk/direct.cpp:
- * 15-48), keeps Li() for nested use (src/librender/integrator.cpp:55-88), and overrides render()
- * (src/librender/integrator.cpp:95-129; precedent in this fork: src/integrators/kk/vcm.cpp:196-218): flatten the scene
- * through public accessors, render on the GPU, hand the ESpectrumAlphaWeight film to Film::put
- * (src/films/hdrfilm.cpp:391-393).
+ * How it attaches to the class that exists: DirectIntegrator is defined INSIDE src/integrators/kk/direct.cpp (:15-196;
+ * there is no direct.h although :2 includes one), with private members brdfSamplesNo / lightSamplesNo / hideEmitters
+ * (:192-194).  So the drop-in is an ADDITION to that class, three lines in kk/direct.cpp (INTEGRATION.md shows the diff):
+ *     - #include "direct.h"                      (:2; the file does not exist)
+ *     + #include "kkintegrator_gpu.h"            (this file: free functions, no class)
+ *     + #include "kk_direct_additions.inl"       (inside the class, before MTS_DECLARE_CLASS(), :180: render() / cancel())
+ * Li(), the constructors, serialize() (size, size, bool: :31-36) and the plugin exports (:198-199) stay as they are, so the
+ * plugin name, the XML parameters, network serialisation and nested use (src/librender/integrator.cpp:55-88) do not change.
+ * Build: the 'kkIntegrator' target (src/integrators/SConscript:44) with -I<repo>/include -I<repo>/adapter, link -lkkdirect.
+ *
+ * What render() then does (src/librender/integrator.cpp:95-129 is the default it overrides; precedent in this fork:
+ * src/integrators/kk/vcm.cpp:196-218): flatten the scene through public accessors, render on the GPU(s), hand the
+ * ESpectrumAlphaWeight film to Film::put (src/films/hdrfilm.cpp:391-393).
  */
+#pragma once
 #include <mitsuba/render/scene.h>
 #include <mitsuba/render/renderqueue.h>
 #include <mitsuba/core/mstream.h>
 #include <mitsuba/core/statistics.h>
+#include <map>
 #include "kkdirect.h"
-#include "direct.h"          /* class DirectIntegrator (the header kk/direct.cpp:2 includes) */
 
 MTS_NAMESPACE_BEGIN
 
-class DirectIntegratorGPU : public DirectIntegrator {
-public:
-    DirectIntegratorGPU(const Properties &props) : DirectIntegrator(props), m_ctx(NULL) { }
-    DirectIntegratorGPU(Stream *stream, InstanceManager *manager) : DirectIntegrator(stream, manager), m_ctx(NULL) { }
+/* what the class keeps between render() and cancel(): the context of the render in flight (cancel() runs on another thread) */
+struct KKDGpuState { kkd_ctx *volatile ctx; KKDGpuState() : ctx(NULL) { } };
 
-    bool render(Scene *scene, RenderQueue *queue, const RenderJob *job, int sceneResID, int sensorResID, int samplerResID) {
+static void kkdOnProgress(void *user, uint64_t done, uint64_t total) {
+    static_cast<ProgressReporter *>(user)->update((size_t) (total ? done * 1000 / total : 1000));
+}
+
+/* SamplingIntegrator::cancel for the GPU render (src/librender/integrator.cpp:90-93) */
+static inline void kkdCancelOnGpu(KKDGpuState *gpu) { kkd_ctx *c = gpu->ctx; if (c) kkd_request_cancel(c); }
+
+/* The body of DirectIntegrator::render(); bsdfSamples / lightSamples / hideEmitters are the class's brdfSamplesNo /
+ * lightSamplesNo / hideEmitters (src/integrators/kk/direct.cpp:17-21, 192-194). */
+static bool kkdRenderOnGpu(Scene *scene, RenderQueue *queue, const RenderJob *job, size_t bsdfSamples, size_t lightSamples,
+                           bool hideEmittersFlag, KKDGpuState *gpu) {
+    {
+        kkd_ctx *&m_ctx = const_cast<kkd_ctx *&>(gpu->ctx);
         /* ---- geometry: Scene::getMeshes() holds the TriMesh of every shape in addShape order, which is the order
          * ShapeKDTree numbers primitives in (src/librender/scene.cpp:558-591, src/librender/skdtree.cpp:49-70), so
          * global primitive id = first_prim + primIndex on both sides ---- */
@@ -44,7 +62,7 @@ public:
         std::map<const BSDF *, int> topLevelOrder;
         for (size_t s = 0; s < meshes.size(); ++s) {
             const BSDF *bsdf = meshes[s]->getBSDF();
-            if (!bsdf) Log(EError, "kkIntegrator: shape %i has no BSDF (index-matched media are not supported)", (int) s);
+            if (!bsdf) SLog(EError, "kkIntegrator: shape %i has no BSDF (index-matched media are not supported)", (int) s);
             if (topLevelOrder.find(bsdf) == topLevelOrder.end()) {
                 topLevelOrder[bsdf] = (int) topLevelOrder.size();
                 im->serialize(ms, bsdf);
@@ -53,7 +71,7 @@ public:
         std::vector<kkd_material> mats(4 * topLevelOrder.size() + 4);
         uint32_t nMats = 0;
         if (kkd_parse_bsdf_stream(ms->getData(), ms->getPos(), &mats[0], (uint32_t) mats.size(), &nMats) != KKD_OK)
-            Log(EError, "kkIntegrator: %s", kkd_last_error(NULL));
+            SLog(EError, "kkIntegrator: %s", kkd_last_error(NULL));
         mats.resize(nMats);
         /* the k-th serialised top-level BSDF is the k-th entry that no earlier entry names as 'nested' */
         std::vector<int> topLevelIndex;
@@ -96,7 +114,7 @@ public:
                 Float r, g, b; p.getSpectrum("radiance", Spectrum::getD65()).toLinearRGB(r, g, b);
                 ke.radiance[0] = r; ke.radiance[1] = g; ke.radiance[2] = b;
                 for (size_t s = 0; s < meshes.size(); ++s) if (meshes[s]->getEmitter() == em) { ke.shape_id = (int32_t) s; shapes[s].emitter_id = (int32_t) e; }
-                if (ke.shape_id < 0) Log(EError, "kkIntegrator: area light %i has no triangle-mesh parent", (int) e);
+                if (ke.shape_id < 0) SLog(EError, "kkIntegrator: area light %i has no triangle-mesh parent", (int) e);
             } else if (plugin == "point") {
                 ke.type = KKD_EMITTER_POINT;
                 Float r, g, b; p.getSpectrum("intensity", Spectrum::getD65()).toLinearRGB(r, g, b);
@@ -115,14 +133,14 @@ public:
                 env.bsphere_center[0] = bs.center.x; env.bsphere_center[1] = bs.center.y; env.bsphere_center[2] = bs.center.z;
                 env.bsphere_radius = bs.radius;
             } else
-                Log(EError, "kkIntegrator: emitter plugin \"%s\" is not on the kk direct path (area, point, envmap)", plugin.c_str());
+                SLog(EError, "kkIntegrator: emitter plugin \"%s\" is not on the kk direct path (area, point, envmap)", plugin.c_str());
             emitters.push_back(ke);
         }
 
         /* ---- sensor, film, reconstruction filter (src/sensors/perspective.cpp:126-180, src/librender/film.cpp:89-96) ---- */
         const Sensor *sensor = scene->getSensor();
         if (sensor->getProperties().getPluginName() != "perspective")
-            Log(EError, "kkIntegrator: only the perspective sensor is on the kk direct path");
+            SLog(EError, "kkIntegrator: only the perspective sensor is on the kk direct path");
         const PerspectiveCamera *cam = static_cast<const PerspectiveCamera *>(sensor);
         const Film *film = sensor->getFilm();
         kkd_sensor ks; memset(&ks, 0, sizeof(ks));
@@ -156,16 +174,16 @@ public:
         kkd_config cfg; memset(&cfg, 0, sizeof(cfg));
         cfg.seed = 1;
         m_ctx = kkd_create(&cfg);
-        if (!m_ctx) Log(EError, "kkIntegrator: %s", kkd_last_error(NULL));          /* throws (src/librender/renderjob.cpp:111-115) */
-        if (kkd_scene_upload(m_ctx, &sd) != KKD_OK) { std::string msg = kkd_last_error(m_ctx); kkd_destroy(m_ctx); m_ctx = NULL; Log(EError, "kkIntegrator: %s", msg.c_str()); }
+        if (!m_ctx) SLog(EError, "kkIntegrator: %s", kkd_last_error(NULL));          /* throws (src/librender/renderjob.cpp:111-115) */
+        if (kkd_scene_upload(m_ctx, &sd) != KKD_OK) { std::string msg = kkd_last_error(m_ctx); kkd_destroy(m_ctx); m_ctx = NULL; SLog(EError, "kkIntegrator: %s", msg.c_str()); }
 
         /* progress: ProgressReporter as BlockedRenderProcess does (src/librender/renderproc.cpp:146, 179) */
         ProgressReporter progress("Rendering", 1000, job);
-        kkd_set_progress_callback(m_ctx, &DirectIntegratorGPU::onProgress, &progress);
+        kkd_set_progress_callback(m_ctx, &kkdOnProgress, &progress);
 
         kkd_render_params rp; memset(&rp, 0, sizeof(rp));
         rp.spp = (uint32_t) scene->getSampler()->getSampleCount();                   /* src/librender/integrator.cpp:103-104 */
-        rp.bsdf_samples = (uint32_t) m_bsdfSamples; rp.light_samples = (uint32_t) m_lightSamples; rp.hide_emitters = m_hideEmitters;
+        rp.bsdf_samples = (uint32_t) bsdfSamples; rp.light_samples = (uint32_t) lightSamples; rp.hide_emitters = hideEmittersFlag ? 1 : 0;
         rp.block_size = scene->getBlockSize(); rp.tile_count = 1;
         ref<ImageBlock> block = new ImageBlock(Bitmap::ESpectrumAlphaWeight, film->getCropSize(), NULL);
         kkd_stats st;
@@ -174,27 +192,16 @@ public:
             block->setOffset(film->getCropOffset());
             const_cast<Film *>(film)->put(block);                                    /* src/films/hdrfilm.cpp:391-393 */
             queue->signalRefresh(job);                                               /* src/librender/renderqueue.cpp:119-141 */
-            Log(EInfo, "kkIntegrator (GPU): %.1f Msamples/s, %.1f Mrays/s, %.2f s", st.samples / st.seconds * 1e-6,
+            SLog(EInfo, "kkIntegrator (GPU): %.1f Msamples/s, %.1f Mrays/s, %.2f s", st.samples / st.seconds * 1e-6,
                 (st.rays_closest + st.rays_shadow) / st.seconds * 1e-6, st.seconds);
         } else if (rc != KKD_ERR_CANCELLED) {
             std::string msg = kkd_last_error(m_ctx); kkd_destroy(m_ctx); m_ctx = NULL;
-            Log(EError, "kkIntegrator: %s", msg.c_str());
+            SLog(EError, "kkIntegrator: %s", msg.c_str());
         }
         kkd_destroy(m_ctx); m_ctx = NULL;
         return rc == KKD_OK;                                                         /* false on cancel (src/librender/integrator.cpp:128) */
     }
 
-    static void onProgress(void *user, uint64_t done, uint64_t total) {
-        static_cast<ProgressReporter *>(user)->update((size_t) (total ? done * 1000 / total : 1000));
-    }
+}
 
-    void cancel() { if (m_ctx) kkd_request_cancel(m_ctx); DirectIntegrator::cancel(); }   /* src/librender/integrator.cpp:90-93 */
-
-    MTS_DECLARE_CLASS()
-private:
-    kkd_ctx *m_ctx;
-};
-
-MTS_IMPLEMENT_CLASS_S(DirectIntegratorGPU, false, DirectIntegrator)
-MTS_EXPORT_PLUGIN(DirectIntegratorGPU, "KK - Direct illumination integrator")       /* same exports: src/libcore/plugin.cpp:78, 96 */
 MTS_NAMESPACE_END

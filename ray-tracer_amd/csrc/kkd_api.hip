@@ -38,6 +38,12 @@ struct DevBuf {
 
 static constexpr int kMaxLanes = 4;
 
+/* developer switches from the environment are performance knobs only, read once and clamped to what the launch code can take */
+static int envInt(const char *text, int dflt, int lo, int hi) {
+    if (!text || !*text) return dflt;
+    return std::max(lo, std::min(hi, atoi(text)));
+}
+
 struct kkd_ctx {
     int device = 0;
     kkd_config cfg{};
@@ -155,8 +161,9 @@ int kkd_scene_upload(kkd_ctx *ctx, const kkd_scene_desc *sd) {
     UP(nodes, hs.bvh.nodes.data(), hs.bvh.nodes.size())
     UP(wideNodes, hs.bvh.wide.data(), hs.bvh.wide.size())
     UP(tris, hs.bvh.tris.data(), hs.bvh.tris.size())
+    std::vector<ProjTri> pt;   /* read by an asynchronous copy: lives until the stream has been synchronised below */
     if (ctx->cfg.flags & KKD_FLAG_PROJECTION_TEST) {
-        std::vector<ProjTri> pt; makeProjTris(hs.bvh.tris, pt);
+        makeProjTris(hs.bvh.tris, pt);
         UP(projTris, pt.data(), pt.size())
     }
     UP(positions, sd->positions, 3 * (size_t)sd->n_verts)
@@ -378,7 +385,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     batch = std::max<uint64_t>(256, (batch + 255) / 256 * 256);
     batch = std::min<uint64_t>(batch, 1ull << 28);
     batch = std::min<uint64_t>(batch, std::max<uint64_t>(256, (total + 255) / 256 * 256));
-    static const int envLanesDefault = [] { const char *e = getenv("KKD_STREAMS"); return e ? atoi(e) : 2; }();
+    static const int envLanesDefault = [] { const char *e = getenv("KKD_STREAMS"); return envInt(e, 2, 1, kMaxLanes); }();
     const int envLanes = (ctx->cfg.flags & KKD_FLAG_ONE_LANE) ? 1 : envLanesDefault;
     if (!ctx->cfg.max_samples_in_flight && envLanes >= 2 && total >= (1ull << 21)) {
         /* library default: an even number of equal batches, so both batch lanes (below) work to the end */
@@ -406,8 +413,8 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     needL(ctx->bsdfRays, S * nB * sizeof(DRay)); needL(ctx->bsdfHits, S * nB * sizeof(DHit)); needL(ctx->brec0, S * nB * 16);
     /* continuation buffer of the two-launch traversal: a quarter of the largest ray launch may be parked */
     /* $KKD_ITER_CAP_CLOSEST / _ANY pin the budgets (0 = one launch, no rounds); else they adapt, see below */
-    static const int envCapClosest = [] { const char *e = getenv("KKD_ITER_CAP_CLOSEST"); return e ? atoi(e) : -1; }();
-    static const int envCapAny = [] { const char *e = getenv("KKD_ITER_CAP_ANY"); return e ? atoi(e) : -1; }();
+    static const int envCapClosest = [] { const char *e = getenv("KKD_ITER_CAP_CLOSEST"); return envInt(e, -1, 0, 4096); }();
+    static const int envCapAny = [] { const char *e = getenv("KKD_ITER_CAP_ANY"); return envInt(e, -1, 0, 4096); }();
     const int capClosest = envCapClosest >= 0 ? envCapClosest : ctx->capClosest, capAny = envCapAny >= 0 ? envCapAny : ctx->capAny;
     const uint64_t contCap = std::min<uint64_t>(((uint64_t)S * std::max(nB, nL) / 2 / kContShards + 128) * kContShards, 0x7fffffffull);   /* two halves of n/4 records */
     needL(ctx->contRecs, contCap * sizeof(ContRec)); needL(ctx->contStacks, contCap * 16 * sizeof(uint32_t)); needL(ctx->contCount, 4 * kContShards * 32 * sizeof(uint32_t));   /* closest: 2 ping-pong counter arrays, any: 2 */
@@ -435,8 +442,8 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         wb.lrec = (float4 *)laneP(ctx->lrec, S * nL * 16, l);
         wb.sampleIdx = nullptr;
     }
-    static const int capLater = [] { const char *e = getenv("KKD_ITER_CAP_LATER"); return e ? atoi(e) : 8; }();
-    static const int rounds = [] { const char *e = getenv("KKD_TRACE_ROUNDS"); return e ? atoi(e) : 2; }();
+    static const int capLater = [] { const char *e = getenv("KKD_ITER_CAP_LATER"); return envInt(e, 8, 1, 4096); }();
+    static const int rounds = [] { const char *e = getenv("KKD_TRACE_ROUNDS"); return envInt(e, 2, 2, 8); }();
     for (int l = 0; l < nLanes; ++l) { contL[l].iterCapLater = capLater; contL[l].rounds = rounds; }
     DeviceCounters *ctr = (DeviceCounters *)ctx->counters.p;
 
@@ -453,7 +460,9 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     bp.edge = edge;
     bp.bs = bs; bp.bsPow2 = (bs & (bs - 1)) == 0; bp.nbx = nbx; bp.nby = nby;
     bp.tileIndex = tileIndex; bp.tileCount = tileCount; bp.nTilesMine = nTilesMine; bp.W = W; bp.H = H;
+#ifdef KKD_ABLATION   /* ablation builds only (scripts/ab*.sh): a release library never reads result-changing switches */
     { const char *dbg = getenv("KKD_DEBUG"); bp.debug = dbg ? (uint32_t)atoi(dbg) : 0u; }
+#endif
 
     const bool count = (ctx->cfg.flags & KKD_FLAG_COUNT_TRAVERSAL) != 0;
     /* one event between consecutive kernels of a batch: 6 per batch, on the stream the kernels run on; events 0 / 1 bracket

@@ -24,6 +24,13 @@
 
 namespace kkd {
 
+/* ablation switches ($KKD_DEBUG bits, kkd_kernels.h) exist only in -DKKD_ABLATION builds; a release build folds them away */
+#ifdef KKD_ABLATION
+__host__ __device__ __forceinline__ bool ablation(const BatchParams &bp, uint32_t bit) { return (bp.debug & bit) != 0u; }
+#else
+__host__ __device__ __forceinline__ constexpr bool ablation(const BatchParams &, uint32_t) { return false; }
+#endif
+
 /* ---- work mapping ------------------------------------------------------------------------------ */
 struct SampleId { int X, Y; uint32_t pixel, sample; bool active; };
 
@@ -614,7 +621,7 @@ __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveB
         const float invNB = frcp((float)nB);
         for (uint32_t b = 0; b < nB; ++b) {                        /* kk/direct.cpp:105-123 + :167-171 */
             const float4 rec = wb.brec0[(size_t)b * bp.stride + i];
-            if (rec.w == 0.f || (bp.debug & 2u)) continue;
+            if (rec.w == 0.f || ablation(bp, 2u)) continue;
             DHit h = wb.bsdfHits[(size_t)b * bp.stride + i];
             if (h.id != kNoHit && (h.id & kHitNotEmitter)) continue;   /* hit a surface that does not emit: Le = 0 */
             if (h.id == kNoHit && sc.envEmitter < 0) continue;
@@ -661,10 +668,10 @@ __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveB
     /* every lane of a group maps to the same pixel, also the inactive ones */
     const int X = s.X, Y = s.Y, W = bp.W, H = bp.H;
     if (g >= 8u && b <= 3) {   /* wave-uniform: groups of g lanes hold the samples of one pixel each */
-        const bool na = (bp.debug & 1u) != 0;
+        const bool na = ablation(bp, 1u);
         /* four waves per pixel: g = 64 lanes per group and the number of groups per pixel a multiple of 4 (batches start
          * at multiples of 256 samples, so a block never straddles two pixels then) */
-        const bool block4 = g == 64u && (bp.chunks & 3u) == 0u && !(bp.debug & 4u);
+        const bool block4 = g == 64u && (bp.chunks & 3u) == 0u && !ablation(bp, 4u);
 #define KKD_SPLAT(BB) switch (g) { \
             case 64u: if (block4) splatGroup<BB, 64, true>(film, sfilter, radius, scale, X, Y, W, H, posx, posy, val, na, sred); \
                       else splatGroup<BB, 64>(film, sfilter, radius, scale, X, Y, W, H, posx, posy, val, na); break; \
@@ -742,7 +749,7 @@ __global__ void __launch_bounds__(256) kDevelop(const float *__restrict__ film, 
 static inline uint32_t blocksFor(uint64_t n, uint32_t block) { return (uint32_t)((n + block - 1) / block); }
 
 void launchPrimary(hipStream_t st, bool count, const DScene &sc, const BatchParams &bp, DHit *hits, DeviceCounters *ctr) {
-    const bool packet = !(bp.debug & 64u);
+    const bool packet = !ablation(bp, 64u);
     const dim3 grid(blocksFor(bp.count, 256 * (packet ? KKD_PRIMARY_RAYS : 1))), block(256);     /* $KKD_DEBUG bit 64: per-lane walk for primary rays (A/B measurements) */
 #define KKD_LP(C, P, K) hipLaunchKernelGGL((kPrimary<C, P, K, kStackLds, 256>), grid, block, 0, st, sc, bp, hits, ctr)
     if (sc.projTris) {

@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs the ablation build: make -C ray-tracer_amd/csrc ablation (the release library ignores $KKD_DEBUG)
 for d in "$@"; do
-  KKD_DEBUG=$d timeout -k 10 200 python -u bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read()); print($d, j['value'], j['roofline']['stage_ms_per_step'])" || exit 1
+  KKD_LIB=$PWD/ray-tracer_amd/lib_ab/libkkdirect.so KKD_DEBUG=$d timeout -k 10 200 python -u bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read()); print($d, j['value'], j['roofline']['stage_ms_per_step'])" || exit 1
 done

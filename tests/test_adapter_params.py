@@ -108,12 +108,18 @@ def test_rejects_what_the_device_path_cannot_take(mutate, msg):
         w2 = Writer(); w2.twosided("t", lambda: w2.diffuse("d", (1, 1, 1))); parse(w2.b, cap=1)
 
 
+def _adapter_source():
+    import os
+    root = os.path.join(os.path.dirname(__file__), "..", "adapter")
+    return open(os.path.join(root, "kkintegrator_gpu.h")).read() + open(os.path.join(root, "kk_direct_additions.inl")).read()
+
+
 def test_adapter_source_uses_only_declared_abi():
-    """adapter/kkintegrator_gpu.cpp cannot be compiled here (no Mitsuba header tree); at least every kkd_* / KKD_* name and
-    every struct field it touches must exist in include/kkdirect.h."""
+    """The adapter cannot be compiled here (no Mitsuba header tree); at least every kkd_* / KKD_* name and every struct
+    field it touches must exist in include/kkdirect.h."""
     import os, re
     root = os.path.join(os.path.dirname(__file__), "..")
-    src = open(os.path.join(root, "adapter", "kkintegrator_gpu.cpp")).read()
+    src = _adapter_source()
     hdr = open(os.path.join(root, "include", "kkdirect.h")).read()
     for name in sorted(set(re.findall(r"\b(?:kkd_[a-z_0-9]+|KKD_[A-Z_0-9]+)\b", src))):
         assert re.search(r"\b%s\b" % name, hdr), name
@@ -123,3 +129,31 @@ def test_adapter_source_uses_only_declared_abi():
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), hdr, re.S).group(1)
         for f in sorted(set(re.findall(r"\b%s\.([a-z_0-9]+)" % var, src))):
             assert re.search(r"\b%s\b" % f, body), (struct, f)
+
+
+REFERENCE_SRC = "/root/reference/src"
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir(REFERENCE_SRC), reason="the reference checkout only exists in the build container")
+def test_adapter_source_uses_names_the_reference_has():
+    """The Mitsuba side of the adapter, checked by grep against the reference's sources: the class it
+    extends is the one kk/direct.cpp defines, with the members that file declares, and every Mitsuba method, type and enum
+    it names occurs in the reference tree."""
+    import os, re, subprocess
+    direct = open(os.path.join(REFERENCE_SRC, "integrators", "kk", "direct.cpp")).read()
+    assert not os.path.exists(os.path.join(REFERENCE_SRC, "integrators", "kk", "direct.h"))       # hence no #include of it
+    inl = open(os.path.join(os.path.dirname(__file__), "..", "adapter", "kk_direct_additions.inl")).read()
+    code = re.sub(r"/\*.*?\*/", "", inl, flags=re.S)
+    for member in ("brdfSamplesNo", "lightSamplesNo", "hideEmitters"):
+        assert re.search(r"\b(size_t|bool) %s;" % member, direct), member
+        assert re.search(r"\b%s\b" % member, code), member
+    assert "class DirectIntegrator : public SamplingIntegrator" in direct and "SamplingIntegrator::cancel()" in code
+    assert '"direct.h"' not in re.sub(r"/\*.*?\*/", "", _adapter_source(), flags=re.S)
+    src = re.sub(r"/\*.*?\*/", "", _adapter_source(), flags=re.S)
+    src = re.sub(r'"(?:[^"\\]|\\.)*"', '""', src)
+    names = set(re.findall(r"(?:->|\.|::)([A-Za-z_][A-Za-z_0-9]*)\s*\(", src)) | set(re.findall(r"\b(E[A-Z][A-Za-z0-9]+)\b", src)) \
+        | set(re.findall(r"\b([A-Z][A-Za-z0-9]+)\s*(?:\*|&|::|<|\()", src))
+    own = {"KKDGpuState"}
+    missing = [n for n in sorted(names - own)
+               if subprocess.run(["grep", "-rwq", n, REFERENCE_SRC, "--include=*.cpp", "--include=*.h"]).returncode != 0]
+    assert not missing, missing

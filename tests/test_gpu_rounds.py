@@ -34,7 +34,11 @@ print("RESULT " + json.dumps(out))
 
 @pytest.mark.parametrize("env", [dict(KKD_ITER_CAP_CLOSEST="3", KKD_ITER_CAP_ANY="2", KKD_ITER_CAP_LATER="2", KKD_TRACE_ROUNDS="5"),
                                  dict(KKD_ITER_CAP_CLOSEST="9", KKD_ITER_CAP_ANY="7", KKD_ITER_CAP_LATER="5", KKD_TRACE_ROUNDS="3"),
-                                 dict(KKD_ITER_CAP_CLOSEST="0", KKD_ITER_CAP_ANY="0")])
+                                 dict(KKD_ITER_CAP_CLOSEST="0", KKD_ITER_CAP_ANY="0"),
+                                 # stray settings must not change a result: the release build ignores the ablation bits of
+                                 # $KKD_DEBUG (they exist only with -DKKD_ABLATION) and clamps the performance knobs
+                                 dict(KKD_DEBUG="7", KKD_STREAMS="-3", KKD_TRACE_ROUNDS="-1", KKD_ITER_CAP_LATER="-5"),
+                                 dict(KKD_DEBUG="71", KKD_STREAMS="99", KKD_TRACE_ROUNDS="1000", KKD_ITER_CAP_CLOSEST="99999")])
 def test_rounds_under_stress_give_the_same_image(gpu, env):
     e = dict(os.environ); e.update(env)
     p = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT, batch=65536)], env=e, capture_output=True, text=True, timeout=280)
