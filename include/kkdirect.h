@@ -287,6 +287,18 @@ int kkd_trace(kkd_ctx *ctx, const float *rays, uint64_t n, int any_hit, kkd_hit 
  * the measurement protocol of src/utils/kdbench.cpp:210-242 times them. */
 int kkd_trace_device(kkd_ctx *ctx, const void *dev_rays, uint64_t n, int any_hit, void *dev_out, kkd_stats *stats);
 
+/* kkd_trace_device for callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  No counterpart in the reference (its CPU path has no device memory to allocate).
+ * Same queries, same results and statistics as kkd_trace_device, but the call makes no hipMalloc / hipFree / event or
+ * stream creation and no host allocation: the sharded ray counters of the launch, which kkd_trace_device keeps in a buffer
+ * of the context, live in a file-scope device array of the library (128 KiB on every GPU the library runs on, held until
+ * the process ends; looked up once per device by kkd_create).  dev_rays / dev_out are caller-owned device memory as for
+ * kkd_trace_device.  At most KKD_NOALLOC_MAX_RAYS rays per call (one launch), more is refused with KKD_ERR_UNSUPPORTED.
+ * All calls on one GPU share that GPU's array: it is cleared at the start of every call, and calls that overlap on one GPU
+ * (two contexts, two threads) race on the counters -- their hits stay correct, their statistics do not. */
+#define KKD_NOALLOC_MAX_RAYS (1ull << 30)
+int kkd_trace_device_noalloc(kkd_ctx *ctx, const void *dev_rays, uint64_t n, int any_hit, void *dev_out, kkd_stats *stats);
+
 /* Counting variant of kkd_trace (host buffers): also reports visited nodes / tested triangles in
  * stats->nodes_visited / tris_tested, the measured N_nodes and N_tris of SURVEY 8d.  Plays the role of the
  * reference's ray statistics counters (src/librender/skdtree.cpp:46-47,123,151,210). */

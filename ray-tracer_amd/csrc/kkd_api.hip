@@ -9,6 +9,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -38,6 +39,31 @@ struct DevBuf {
 
 static constexpr int kMaxLanes = 4;
 
+/* ---- scratch of the entry point that allocates nothing (kkd_trace_device_noalloc) ----------------------------------
+ * The sharded ray / traversal counters of a trace launch (kCounterShards lines of 128 bytes = 128 KiB), which the other
+ * entry points keep in a hipMalloc'ed buffer of the context.  Every GPU the library runs on holds its own copy of this
+ * array until the process ends.  In host code the array's NAME is only a stand-in for the symbol, not a device address:
+ * the address on a device comes from hipGetSymbolAddress, once per device with that device current (scratchForDevice,
+ * called by kkd_create), and only that pointer is handed to hipMemsetAsync, the copies and the kernels. */
+static __device__ __align__(256) unsigned char g_noallocScratch[kCounterShards * sizeof(DeviceCounters)];
+static constexpr int kMaxDevices = 64;
+static void *g_noallocScratchPtr[kMaxDevices];      /* per device: address of that device's copy, nullptr until looked up */
+static std::mutex g_noallocMutex;
+
+/* device must be current */
+static hipError_t scratchForDevice(int device, void **out) {
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_noallocMutex);
+    if (!g_noallocScratchPtr[device]) {
+        void *p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_noallocScratch));
+        if (e != hipSuccess) return e;
+        g_noallocScratchPtr[device] = p;
+    }
+    *out = g_noallocScratchPtr[device];
+    return hipSuccess;
+}
+
 /* developer switches from the environment are performance knobs only, read once and clamped to what the launch code can take */
 static int envInt(const char *text, int dflt, int lo, int hi) {
     if (!text || !*text) return dflt;
@@ -65,6 +91,11 @@ struct kkd_ctx {
     std::vector<hipEvent_t> events;
     std::vector<hipEvent_t> doneEvents;   /* one per batch in flight: recorded after the batch's splat (progress reports) */
     kkd_progress_fn progressFn = nullptr; void *progressUser = nullptr;
+    /* set up by kkd_create so that kkd_trace_device_noalloc never allocates: this device's scratch array, two timing
+     * events, a pinned host copy of the counter shards */
+    void *noallocScratch = nullptr;
+    hipEvent_t traceEv[2] = { nullptr, nullptr };
+    DeviceCounters *hostShards = nullptr;
 };
 
 #define KKD_HIP(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
@@ -99,6 +130,11 @@ kkd_ctx *kkd_create(const kkd_config *cfg) {
     ctx->device = cfg->device; ctx->cfg = *cfg;
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { g_globalError = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete ctx; return nullptr; }
+    e = scratchForDevice(cfg->device, &ctx->noallocScratch);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->traceEv[0]);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->traceEv[1]);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->hostShards, kCounterShards * sizeof(DeviceCounters), hipHostMallocDefault);
+    if (e != hipSuccess) { g_globalError = std::string("kkd_create: ") + hipGetErrorString(e); kkd_destroy(ctx); return nullptr; }
     g_globalError = "";
     return ctx;
 }
@@ -141,6 +177,8 @@ void kkd_destroy(kkd_ctx *ctx) {
     for (DevBuf *b : all) b->release();
     for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->doneEvents) hipEventDestroy(ev);
+    for (hipEvent_t ev : ctx->traceEv) if (ev) hipEventDestroy(ev);
+    if (ctx->hostShards) hipHostFree(ctx->hostShards);
     for (hipStream_t s : ctx->laneStreams) if (s) hipStreamDestroy(s);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -259,9 +297,10 @@ int kkd_develop(kkd_ctx *ctx, const float *film, uint32_t width, uint32_t height
     return KKD_OK;
 }
 
-static DeviceCounters sumShards(const std::vector<DeviceCounters> &shards) {
+static DeviceCounters sumShards(const DeviceCounters *shards, size_t n) {
     DeviceCounters c; std::memset(&c, 0, sizeof(c));
-    for (const DeviceCounters &s : shards) {
+    for (size_t k = 0; k < n; ++k) {
+        const DeviceCounters &s = shards[k];
         c.samples += s.samples;
         for (int k = 0; k < 3; ++k) c.parked[k] += s.parked[k];
         for (int k = 0; k < 3; ++k) { c.rays[k] += s.rays[k]; c.nodes[k] += s.nodes[k]; c.tris[k] += s.tris[k]; }
@@ -285,29 +324,30 @@ static void fillCounterStats(kkd_stats *stats, const DeviceCounters &c, bool cou
 }
 
 /* ---- fixed ray sets ---- */
-static int traceImpl(kkd_ctx *ctx, const void *devRays, uint64_t n, int anyHit, void *devOut, bool count, kkd_stats *stats) {
+/* noAlloc: the variant behind kkd_trace_device_noalloc -- counters in this device's static scratch array, the events and
+ * the host copy of the shards created by kkd_create: no hipMalloc / hipFree / hipEventCreate / host allocation in here. */
+static int traceImpl(kkd_ctx *ctx, const void *devRays, uint64_t n, int anyHit, void *devOut, bool count, kkd_stats *stats, bool noAlloc = false) {
     if (!ctx->haveScene) return fail(ctx, KKD_ERR_INVALID, "no scene uploaded");
     KKD_HIP(ctx, hipSetDevice(ctx->device));
-    KKD_HIP(ctx, ctx->counters.ensure(kCounterShards * sizeof(DeviceCounters)));
-    KKD_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, kCounterShards * sizeof(DeviceCounters), ctx->stream));
-    hipEvent_t e0, e1;
-    KKD_HIP(ctx, hipEventCreate(&e0)); KKD_HIP(ctx, hipEventCreate(&e1));
+    if (!noAlloc) KKD_HIP(ctx, ctx->counters.ensure(kCounterShards * sizeof(DeviceCounters)));
+    DeviceCounters *ctr = (DeviceCounters *)(noAlloc ? ctx->noallocScratch : ctx->counters.p);
+    /* the array keeps the last call's contents: the counters must start at zero */
+    KKD_HIP(ctx, hipMemsetAsync(ctr, 0, kCounterShards * sizeof(DeviceCounters), ctx->stream));
+    const hipEvent_t e0 = ctx->traceEv[0], e1 = ctx->traceEv[1];
     KKD_HIP(ctx, hipEventRecord(e0, ctx->stream));
     const uint64_t chunk = 1ull << 30;   /* keep grid sizes within 32 bits */
     for (uint64_t off = 0; off < n; off += chunk) {
         const uint64_t m = std::min(chunk, n - off);
-        launchTrace(ctx->stream, ctx->ds, (const DRay *)devRays + off, m, anyHit != 0, count, 1, (DHit *)devOut + off, (DeviceCounters *)ctx->counters.p,
+        launchTrace(ctx->stream, ctx->ds, (const DRay *)devRays + off, m, anyHit != 0, count, 1, (DHit *)devOut + off, ctr,
                     anyHit ? KKD_RAYS_SHADOW : KKD_RAYS_BSDF);
     }
     KKD_HIP(ctx, hipGetLastError());
     KKD_HIP(ctx, hipEventRecord(e1, ctx->stream));
-    std::vector<DeviceCounters> shards(kCounterShards);
-    KKD_HIP(ctx, hipMemcpyAsync(shards.data(), ctx->counters.p, kCounterShards * sizeof(DeviceCounters), hipMemcpyDeviceToHost, ctx->stream));
+    KKD_HIP(ctx, hipMemcpyAsync(ctx->hostShards, ctr, kCounterShards * sizeof(DeviceCounters), hipMemcpyDeviceToHost, ctx->stream));
     KKD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const DeviceCounters c = sumShards(shards);
+    const DeviceCounters c = sumShards(ctx->hostShards, kCounterShards);
     float ms = 0.f;
     KKD_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0); hipEventDestroy(e1);
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         fillCounterStats(stats, c, count);
@@ -324,6 +364,16 @@ int kkd_trace_device(kkd_ctx *ctx, const void *dev_rays, uint64_t n, int any_hit
     if (!ctx) return KKD_ERR_INVALID;
     if (n && (!dev_rays || !dev_out)) return fail(ctx, KKD_ERR_INVALID, "kkd_trace_device: NULL buffer");
     return traceImpl(ctx, dev_rays, n, any_hit, dev_out, false, stats);
+}
+
+/* The entry point that allocates nothing (include/kkdirect.h): kkd_trace_device with the counter shards in the static
+ * device array above.  One launch, so n is bounded by the largest grid. */
+int kkd_trace_device_noalloc(kkd_ctx *ctx, const void *dev_rays, uint64_t n, int any_hit, void *dev_out, kkd_stats *stats) {
+    if (!ctx) return KKD_ERR_INVALID;
+    if (n > KKD_NOALLOC_MAX_RAYS) return fail(ctx, KKD_ERR_UNSUPPORTED, "kkd_trace_device_noalloc: more than KKD_NOALLOC_MAX_RAYS (2^30) rays in one call");
+    if (n && (!dev_rays || !dev_out)) return fail(ctx, KKD_ERR_INVALID, "kkd_trace_device_noalloc: NULL buffer");
+    if (!ctx->noallocScratch) return fail(ctx, KKD_ERR_DEVICE, "kkd_trace_device_noalloc: no scratch array on this device");
+    return traceImpl(ctx, dev_rays, n, any_hit, dev_out, false, stats, true);
 }
 
 static int traceHost(kkd_ctx *ctx, const float *rays, uint64_t n, int anyHit, kkd_hit *out, bool count, kkd_stats *stats) {
@@ -601,7 +651,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     KKD_HIP(ctx, hipMemcpyAsync(shards.data(), ctr, kCounterShards * sizeof(DeviceCounters), hipMemcpyDeviceToHost, st0));
     KKD_HIP(ctx, hipStreamSynchronize(st0));
     pollProgress(true);
-    const DeviceCounters c = sumShards(shards);
+    const DeviceCounters c = sumShards(shards.data(), shards.size());
     {
         /* Budget control over the whole render: too many parked rays and the second round repeats their set-up for
          * nothing, too few and the first round idles in its tail.  On C2 and C4 the best fixed budgets park 8-16 % of the traced rays. */

@@ -136,6 +136,13 @@ class Context:
         self._check(self.lib.kkd_trace_device(self.h, C.c_void_p(dev_rays), n, int(any_hit), C.c_void_p(dev_out), C.byref(st)))
         return st
 
+    def trace_device_noalloc(self, dev_rays, n, dev_out, any_hit=False):
+        """kkd_trace_device_noalloc: the same queries without any allocation inside the call (counters in the library's
+        static device array)."""
+        st = abi.Stats()
+        self._check(self.lib.kkd_trace_device_noalloc(self.h, C.c_void_p(dev_rays), n, int(any_hit), C.c_void_p(dev_out), C.byref(st)))
+        return st
+
     def develop(self, film, pixel_format="rgb"):
         """HDRFilm::develop / MFilm::develop on the GPU: film H x W x 5 -> H x W x channels float32 (kkd_develop)."""
         fmt = abi.PIXEL_FORMATS[pixel_format.lower()] if isinstance(pixel_format, str) else int(pixel_format)

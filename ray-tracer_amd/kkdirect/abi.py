@@ -17,6 +17,7 @@ SHAPE_HAS_NORMALS, SHAPE_HAS_TEXCOORDS = 1, 2
 FLAG_COUNT_TRAVERSAL = 1
 FLAG_PROJECTION_TEST = 2
 FLAG_ONE_LANE = 4
+NOALLOC_MAX_RAYS = 1 << 30      # KKD_NOALLOC_MAX_RAYS
 PIXEL_LUMINANCE, PIXEL_LUMINANCE_ALPHA, PIXEL_RGB, PIXEL_RGBA, PIXEL_XYZ, PIXEL_XYZA = range(6)
 PIXEL_CHANNELS = {PIXEL_LUMINANCE: 1, PIXEL_LUMINANCE_ALPHA: 2, PIXEL_RGB: 3, PIXEL_RGBA: 4, PIXEL_XYZ: 3, PIXEL_XYZA: 4}
 PIXEL_FORMATS = {"luminance": PIXEL_LUMINANCE, "luminancealpha": PIXEL_LUMINANCE_ALPHA, "rgb": PIXEL_RGB, "rgba": PIXEL_RGBA,
@@ -110,6 +111,7 @@ ENTRY_POINTS = {
     "kkd_render_device": (C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]),
     "kkd_trace": (C.c_int, [C.c_void_p, pf32, u64, C.c_int, C.POINTER(Hit)]),
     "kkd_trace_device": (C.c_int, [C.c_void_p, C.c_void_p, u64, C.c_int, C.c_void_p, C.POINTER(Stats)]),
+    "kkd_trace_device_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, u64, C.c_int, C.c_void_p, C.POINTER(Stats)]),
     "kkd_trace_counted": (C.c_int, [C.c_void_p, pf32, u64, C.c_int, C.POINTER(Hit), C.POINTER(Stats)]),
     "kkd_accel_info": (C.c_int, [C.c_void_p, pu32, pu32, C.POINTER(u64), C.POINTER(u64)]),
     "kkd_probe_rough_transmittance": (C.c_int, [C.c_int, C.c_float, C.c_float, pf32, pf32]),
