@@ -20,6 +20,9 @@
 #include <vector>
 #include <cstdio>
 #include <cassert>
+#include <atomic>
+#include <cstdlib>
+#include <thread>
 
 namespace ora {
 
@@ -222,7 +225,20 @@ public:
         nodes.clear(); indices.clear();
         nodes.reserve(n / 2 + 16);
         nodes.push_back(KDNode());
+        /* Subtrees of at most kTaskPrims primitives are independent of each other (a subtree is a function of its cell, its
+         * primitive list, their clipped boxes, depth and bad-refine count), so the top of the tree is built here and the
+         * subtrees below it on worker threads into fragments that are spliced in afterwards -- the reference builds in
+         * parallel too (kdParallelBuild, scene.cpp:66-69).  Same tree as the sequential build, other node order in memory. */
+        deferBelow = buildThreads() > 1 ? kTaskPrims : 0;
+        tasks.clear();
         buildRec(0, aabb, prims, boxes, 0, maxDepth, 0);
+        deferBelow = 0;
+        if (!tasks.empty()) runTasks(boxes, maxDepth);
+    }
+    static unsigned buildThreads() {
+        const char *e = std::getenv("KKORACLE_BUILD_THREADS");
+        unsigned t = e ? (unsigned)std::atoi(e) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        return std::max(1u, t);
     }
 
     /* stats (nullable): [0] += visited nodes, [1] += tested triangles (N_nodes / N_tris of SURVEY 8d) */
@@ -288,12 +304,56 @@ public:
 private:
     MeshView mesh;
     struct Event { Float pos; uint32_t prim; uint8_t type; /* 0 = end, 1 = planar, 2 = start */ };
+    static constexpr uint32_t kTaskPrims = 131072;
+    struct Task { uint32_t nodeIdx; AABB cell; std::vector<uint32_t> prims; std::vector<AABB> primBoxes; int depth, badRefines; };
+    std::vector<Task> tasks;
+    uint32_t deferBelow = 0;      /* > 0 while the top of the tree is built: subtrees of <= that many primitives become tasks */
+
+    void runTasks(const std::vector<AABB> &boxes, int maxDepth) {
+        std::vector<KDTree> frags(tasks.size());
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= tasks.size()) return;
+                Task &t = tasks[k]; KDTree &f = frags[k];
+                f.mesh = mesh;
+                /* a private box table for the task's primitives (the recursion clips boxes in place), addressed by local id */
+                std::vector<uint32_t> local(t.prims.size());
+                for (uint32_t i = 0; i < (uint32_t)local.size(); ++i) local[i] = i;
+                f.globalId = t.prims;
+                f.nodes.push_back(KDNode());
+                f.buildRec(0, t.cell, local, t.primBoxes, t.depth, maxDepth, t.badRefines);
+                std::vector<AABB>().swap(t.primBoxes);
+            }
+        };
+        std::vector<std::thread> pool;
+        const unsigned nt = std::min<unsigned>(buildThreads(), (unsigned)tasks.size());
+        for (unsigned i = 0; i < nt; ++i) pool.emplace_back(worker);
+        for (auto &th : pool) th.join();
+        for (size_t k = 0; k < tasks.size(); ++k) {      /* splice: fragment node 0 -> the task's node, the rest appended */
+            const KDTree &f = frags[k];
+            const uint32_t nodeOff = (uint32_t)nodes.size() - 1u, idxOff = (uint32_t)indices.size();
+            auto fix = [&](KDNode nd) {
+                if (nd.isLeaf()) { nd.combined = ((nd.combined & ~kLeafFlag) + idxOff) | kLeafFlag; nd.primEnd += idxOff; }
+                else nd.combined = ((((nd.combined >> 2) + nodeOff)) << 2) | (nd.combined & 3u);
+                return nd;
+            };
+            nodes[tasks[k].nodeIdx] = fix(f.nodes[0]);
+            for (size_t j = 1; j < f.nodes.size(); ++j) nodes.push_back(fix(f.nodes[j]));
+            indices.insert(indices.end(), f.indices.begin(), f.indices.end());
+            maxDepthSeen = std::max(maxDepthSeen, f.maxDepthSeen);
+        }
+        tasks.clear();
+    }
+    std::vector<uint32_t> globalId;   /* fragment builds: local primitive id -> primitive; empty = identity */
+    uint32_t gid(uint32_t p) const { return globalId.empty() ? p : globalId[p]; }
 
     void makeLeaf(uint32_t nodeIdx, const std::vector<uint32_t> &prims, int depth) {
         maxDepthSeen = std::max(maxDepthSeen, depth);
         KDNode &nd = nodes[nodeIdx];
         nd.combined = (uint32_t)indices.size() | kLeafFlag;
-        for (uint32_t p : prims) indices.push_back(p);
+        for (uint32_t p : prims) indices.push_back(gid(p));
         nd.primEnd = (uint32_t)indices.size();
     }
 
@@ -301,6 +361,14 @@ private:
                   int depth, int maxDepth, int badRefines) {
         const uint32_t n = (uint32_t)prims.size();
         if (n <= (uint32_t)kStopPrims || depth >= maxDepth) { makeLeaf(nodeIdx, prims, depth); return; }
+        if (deferBelow && n <= deferBelow) {
+            Task t; t.nodeIdx = nodeIdx; t.cell = box; t.depth = depth; t.badRefines = badRefines;
+            t.primBoxes.resize(n);
+            for (uint32_t i = 0; i < n; ++i) t.primBoxes[i] = boxes[prims[i]];
+            t.prims.swap(prims);
+            tasks.push_back(std::move(t));
+            return;
+        }
         const Float invSA = 1.0f / box.surfaceArea();
         const Float leafCost = kQueryCost * n;
         int bestAxis = -1; Float bestPos = 0, bestCost = std::numeric_limits<Float>::infinity();
@@ -401,7 +469,8 @@ private:
             if (inside) { kept.push_back(p); continue; }
             AABB nb;
             if (exact) {
-                nb = triClippedAABB(mesh.P(mesh.idx[3 * p]), mesh.P(mesh.idx[3 * p + 1]), mesh.P(mesh.idx[3 * p + 2]), cell);
+                const uint32_t g = gid(p);
+                nb = triClippedAABB(mesh.P(mesh.idx[3 * g]), mesh.P(mesh.idx[3 * g + 1]), mesh.P(mesh.idx[3 * g + 2]), cell);
                 if (!nb.isValid()) continue;      /* clipped away entirely */
             } else { nb = b; nb.clip(cell); }
             saved.push_back(std::make_pair(p, b));
