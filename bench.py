@@ -4,12 +4,21 @@ Mrays/s, fraction of the HBM roofline, CPU baseline beside it).
 
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
 
-One step = one full render pass of the workload (default C2 of BASELINE.json: Sponza-class interior,
-~260k triangles, 1920x1080, 256 spp, bsdfSamples = lightSamples = 1).  With N ranks the image tiles are
-sharded round-robin over the ranks (tile_index = rank, tile_count = N, no collective while rendering)
-and every rank renders N x 256 spp of its tiles, so per-GPU work is constant (weak scaling); the films
-are merged by one RCCL sum-reduce per step (what Film::put(block) does in the reference), inside the
+One step = one full render pass of the workload.  Default = C4 of BASELINE.json, the largest single-GPU
+configuration and the north-star target: 10.7 M-triangle displaced mesh under a 4096x2048 HDR envmap,
+roughconductor / dielectric, 3840x2160, 512 spp, bsdfSamples = lightSamples = 1 (C2, the Sponza-class
+1080p scene, is timed briefly in the same run and reported under "secondary").  With N ranks the image
+tiles are sharded round-robin over the ranks (tile_index = rank, tile_count = N, no collective while
+rendering) and every rank renders N x spp of its tiles, so per-GPU work is constant (weak scaling); the
+films are merged by one RCCL sum-reduce per step (what Film::put(block) does in the reference), inside the
 timed region.  --split sample renders the whole frame on every rank with disjoint sample ranges instead.
+
+Roofline (dominant kernel): `achieved` = algorithmic bytes per launch (rays x (io + nodes/ray x
+node bytes + tris/ray x triangle bytes), the per-ray counts measured by a counting pass of the same
+traversal in this run) / the HIP-event launch duration measured in this run, against the 8 TB/s HBM peak;
+`traffic` = HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (used only when
+they were taken on this workload with this batch size).  Cache-resident workloads (C1-C3) can exceed the
+HBM peak in algorithmic bytes; their line then reports against the L2 gather ceiling and says so.
 """
 import argparse
 import ctypes
@@ -24,6 +33,8 @@ sys.path.insert(0, os.path.join(ROOT, "ray-tracer_amd"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+# MI355X_MICROARCH.md, 'Indexed rows: gather': chip-wide rates of divergent row gathers by where the rows are served from
+GATHER_CEILINGS_GBS = {"l2_resident_rows": 17800.0, "infinity_cache_random_rows": 8600.0, "beyond_infinity_cache_random_rows": 5600.0}
 
 
 def make_workload(name, scale):
@@ -59,7 +70,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4"])
+    ap.add_argument("--workload", default="c4", choices=["c1", "c2", "c3", "c4"])
+    ap.add_argument("--no-extra-passes", action="store_true", help="timed region only: no counting pass, no one-lane pass, no secondary workload (profiler runs)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short C2 measurement reported under 'secondary'")
     ap.add_argument("--split", default="tile", choices=["tile", "sample"])
     ap.add_argument("--spp", type=int, default=0, help="override the workload's spp (then the line is not the headline config)")
     ap.add_argument("--scale", type=float, default=1.0, help="resolution scale (debug only)")
@@ -152,61 +165,15 @@ def main():
 
     out = None
     if rank == 0:
-        # ---- roofline of the dominant kernel: HIP-event stage times of the timed steps (recorded by the library on
-        # the stream its kernels run on) against algorithmic bytes from a counting pass of the same traversal ----
-        cctx = kkdirect.Context(device=local_rank, seed=1, count_traversal=True, projection_test=proj).upload(scene)
-        _, cst = cctx.render(min(spp, 8), n_b, n_l, **{k: v for k, v in kw.items() if k not in ("spp", "sample_first")})
-        cctx.close()
-        per_ray = [(cst.class_nodes[k] / max(1, cst.class_rays[k]), cst.class_tris[k] / max(1, cst.class_rays[k])) for k in range(3)]
-        # In the timed region two batches of camera samples are in flight on two streams, so a kernel's event duration
-        # there includes the other lane's kernels sharing the GPU.  The roofline of a kernel needs its exclusive duration:
-        # the same renders are repeated with KKD_FLAG_ONE_LANE (same kernels, same batches, one stream) right here and
-        # the HIP-event stage times of THAT pass are used; the timed region's shared durations are reported beside them.
-        shared_s = [sum(s.stage_seconds[k] for s in stats) for k in range(5)]
-        shared_n = [sum(s.stage_launches[k] for s in stats) for k in range(5)]
-        xctx = kkdirect.Context(device=local_rank, seed=1, max_samples_in_flight=args.batch, projection_test=proj, one_lane=True).upload(scene)
-        xctx.render_device(film.data_ptr(), bsdf_samples=n_b, light_samples=n_l, **kw)          # warm-up (budgets adapt)
-        xstats = [xctx.render_device(film.data_ptr(), bsdf_samples=n_b, light_samples=n_l, **kw) for _ in range(args.steps)]
-        one_lane_ms = sum(s.seconds for s in xstats) / args.steps * 1e3
-        xctx.close()
-        stage_s = [sum(s.stage_seconds[k] for s in xstats) for k in range(5)]
-        stage_n = [sum(s.stage_launches[k] for s in xstats) for k in range(5)]
-        acc = ctx.accel_info()
-        bytes_k = [sum(stage_bytes(s, n_b, n_l, per_ray, acc["node_bytes"], acc["tri_bytes"])[k] for s in xstats) for k in range(5)]
-        dom = int(np.argmax(stage_s)) if sum(stage_s) > 0 else 2    # the path plugin times the render only, not its stages
-        avg_launch_s = stage_s[dom] / max(1, stage_n[dom])
-        achieved = bytes_k[dom] / max(1, stage_n[dom]) / max(avg_launch_s, 1e-12) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get(abi.STAGE_NAMES[dom])
-            except Exception:
-                traffic = None
-        kernel_note = {"bsdf": "bsdf = kTraceRound<closest> (first round + resume round: 2 launches per batch, averaged)",
-                       "shadow": "shadow = kTraceRound<any> (first round + resume round: 2 launches per batch, averaged)"}
-        roofline = {"bound": "hbm", "kernel": kernel_note.get(abi.STAGE_NAMES[dom], abi.STAGE_NAMES[dom]), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    # algorithmic bytes count every node / triangle visit; the visits are served by L1/L2, so the
-                    # figure can exceed the HBM peak -- the measured HBM side of the same launch is reported beside it
-                    "traffic_gbps": None if traffic is None else round(traffic / max(avg_launch_s, 1e-12) / 1e9, 2),
-                    "traffic_frac": None if traffic is None else round(traffic / max(avg_launch_s, 1e-12) / 1e9 / HBM_PEAK_GBS, 5),
-                    "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": stage_n[dom],
-                    "measured": "one-lane pass (KKD_FLAG_ONE_LANE) of the same renders inside this run: exclusive kernel durations",
-                    "avg_launch_ms_timed_region": round(shared_s[dom] / max(1, shared_n[dom]) * 1e3, 4),
-                    "one_lane_ms_per_step": round(one_lane_ms, 3),
-                    "algorithmic_bytes_per_launch": round(bytes_k[dom] / max(1, stage_n[dom])),
-                    "nodes_per_ray": [round(p[0], 2) for p in per_ray], "tris_per_ray": [round(p[1], 2) for p in per_ray],
-                    # whole job: algorithmic bytes of all five stages per second of the timed region, and the
-                    # compulsory lower bound (scene structures read once + film written once) the re-reads are measured against
-                    "job_algorithmic_gbps": round(sum(sum(stage_bytes(s_, n_b, n_l, per_ray, acc["node_bytes"], acc["tri_bytes"])) for s_ in stats) / elapsed / 1e9, 2),
-                    "compulsory_bytes_per_step": int(acc["n_nodes"] * (acc["node_bytes"] + 128) + acc["n_leaf_tris"] * acc["tri_bytes"]
-                                                     + scene._nv * (12 + 12 + 8) + scene._nt * 12 + W * H * 5 * 4),
-                    "stage_ms_per_step": {abi.STAGE_NAMES[k]: round(stage_s[k] / args.steps * 1e3, 3) for k in range(5)},
-                    "stage_ms_per_step_timed_region": {abi.STAGE_NAMES[k]: round(shared_s[k] / args.steps * 1e3, 3) for k in range(5)}}
+        roofline = None
+        if not args.no_extra_passes:
+            roofline = measure_roofline(ctx, scene, args, kw, n_b, n_l, spp, film, stats, elapsed, local_rank, proj, W, H)
         cpu = None
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not args.no_extra_passes:
             cpu = cpu_baseline(scene, n_b, n_l, W, H)
+        secondary = None
+        if world == 1 and args.workload == "c4" and args.integrator == "kk" and not (args.no_secondary or args.no_extra_passes or args.spp or args.scale != 1.0):
+            secondary = secondary_c2(local_rank, proj)
         out = {
             "metric": "Msamples/s (kk direct integrator)" if args.integrator == "kk" else "Msamples/s (%s plugin, not the headline metric)" % args.integrator, "value": round(samples / elapsed / 1e6, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -215,14 +182,121 @@ def main():
             "config": {"workload": label, "spp_total": kw["spp"] if args.split == "tile" else spp * world, "bsdfSamples": n_b, "lightSamples": n_l,
                        "integrator": args.integrator, "max_depth": args.max_depth if args.integrator == "path" else None,
                        "split": args.split, "backend": backend, "leaf_test": args.leaf_test, "triangles": int(scene._nt), "scene_upload_s": round(upload_s, 2)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary,
         }
+        if args.no_extra_passes:     # profiler runs: what scripts/summarize_pmc.py keys the counters by
+            out["pmc_samples_per_batch"] = round(samples / max(1, sum(s.stage_launches[1] for s in stats)))
     ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out), flush=True)
+
+
+def load_pmc(workload, stage, samples_per_batch):
+    """HBM traffic / L2 hit rate / issue counters of one kernel stage from the committed PMC summary
+    (profiles/pmc_traffic.json, written by scripts/summarize_pmc.py from separate rocprofv3 --pmc passes).  Only
+    returned when the passes were taken on this workload with the same number of camera samples per batch (within 2 %):
+    traffic per launch scales with the batch, not with spp."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(path)).get(workload)
+        if not rec or abs(rec["samples_per_batch"] - samples_per_batch) > 0.02 * samples_per_batch:
+            return None
+        return rec["stages"].get(stage)
+    except Exception:
+        return None
+
+
+def measure_roofline(ctx, scene, args, kw, n_b, n_l, spp, film, stats, elapsed, device, proj, W, H):
+    """Roofline of the dominant kernel stage.  Durations: HIP events the library records between the kernels, on the
+    stream they run on.  In the timed region two batches of camera samples are in flight on two streams, so an event
+    interval there includes the other lane's kernels; the kernel's exclusive duration comes from a short one-lane pass
+    (KKD_FLAG_ONE_LANE: same kernels, same batches, one stream) of the same render right here."""
+    import kkdirect
+    from kkdirect import abi
+    # nodes / triangles per ray of each ray class: counting build of the same traversal, low spp
+    cctx = kkdirect.Context(device=device, seed=1, count_traversal=True, projection_test=proj).upload(scene)
+    _, cst = cctx.render(min(spp, 8), n_b, n_l, **{k: v for k, v in kw.items() if k not in ("spp", "sample_first")})
+    cctx.close()
+    per_ray = [(cst.class_nodes[k] / max(1, cst.class_rays[k]), cst.class_tris[k] / max(1, cst.class_rays[k])) for k in range(3)]
+    shared_s = [sum(s.stage_seconds[k] for s in stats) for k in range(5)]
+    shared_n = [sum(s.stage_launches[k] for s in stats) for k in range(5)]
+    x_steps = max(1, min(args.steps, 3))
+    xctx = kkdirect.Context(device=device, seed=1, max_samples_in_flight=args.batch, projection_test=proj, one_lane=True).upload(scene)
+    xctx.render_device(film.data_ptr(), bsdf_samples=n_b, light_samples=n_l, **kw)          # warm-up (budgets adapt)
+    xstats = [xctx.render_device(film.data_ptr(), bsdf_samples=n_b, light_samples=n_l, **kw) for _ in range(x_steps)]
+    one_lane_ms = sum(s.seconds for s in xstats) / x_steps * 1e3
+    xctx.close()
+    stage_s = [sum(s.stage_seconds[k] for s in xstats) for k in range(5)]
+    stage_n = [sum(s.stage_launches[k] for s in xstats) for k in range(5)]
+    acc = ctx.accel_info()
+    bytes_k = [sum(stage_bytes(s, n_b, n_l, per_ray, acc["node_bytes"], acc["tri_bytes"])[k] for s in xstats) for k in range(5)]
+    dom = int(np.argmax(stage_s)) if sum(stage_s) > 0 else 2    # the path plugin times the render only, not its stages
+    name = abi.STAGE_NAMES[dom]
+    launches = max(1, stage_n[dom])
+    avg_launch_s = max(stage_s[dom] / launches, 1e-12)
+    alg_per_launch = bytes_k[dom] / launches
+    achieved = alg_per_launch / avg_launch_s / 1e9
+    ray_class = {0: 0, 2: 1, 3: 2}.get(dom)
+    rays_per_launch = None if ray_class is None else sum(s.class_rays[ray_class] for s in xstats) / launches
+    samples_per_batch = sum(s.samples for s in xstats) / max(1, stage_n[1])      # kShade runs once per batch
+    pmc = None if args.scale != 1.0 else load_pmc(args.workload, name, samples_per_batch)    # another resolution is another workload
+    traffic = None if pmc is None else pmc["hbm_bytes_per_launch"]
+    kernel_note = {"bsdf": "bsdf = kTraceRound<closest> (first round + resume round: 2 launches per batch, averaged)",
+                   "shadow": "shadow = kTraceRound<any> (first round + resume round: 2 launches per batch, averaged)"}
+    hbm_frac = achieved / HBM_PEAK_GBS
+    r = {"bound": "hbm", "kernel": kernel_note.get(name, name), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(hbm_frac, 5), "traffic": traffic}
+    if hbm_frac > 1.0:
+        # more algorithmic bytes per second than HBM can deliver: the visits are served by L1 / L2 / Infinity Cache, an HBM
+        # fraction is meaningless here; report against the guide's L2-resident gather rate instead and say so
+        peak = GATHER_CEILINGS_GBS["l2_resident_rows"]
+        r.update({"bound": "l2-gather (cache-resident tree: algorithmic bytes exceed the HBM peak)", "peak": peak, "frac": round(achieved / peak, 5)})
+    r.update({
+        # the measured HBM side of the same kernel (PMC: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, gfx950 correction of
+        # MI355X_MICROARCH.md; FETCH_SIZE includes Infinity-Cache hits, so this is an upper bound of the DRAM traffic)
+        "hbm_measured_gbps": None if traffic is None else round(traffic / avg_launch_s / 1e9, 2),
+        "hbm_measured_frac": None if traffic is None else round(traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS, 5),
+        "l2_hit_rate": None if pmc is None else pmc.get("l2_hit_rate"),
+        "valu_issue_util": None if pmc is None else pmc.get("valu_issue_util"),
+        "pmc_source": None if pmc is None else "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, same workload and batch size)",
+        "algorithmic_vs_gather_ceilings": {k: round(achieved / v, 4) for k, v in GATHER_CEILINGS_GBS.items()},
+        "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": stage_n[dom], "rays_per_launch": None if rays_per_launch is None else round(rays_per_launch), "samples_per_batch": round(samples_per_batch),
+        "measured": "one-lane pass (KKD_FLAG_ONE_LANE) of the same render inside this run, %d steps: exclusive kernel durations" % x_steps,
+        "avg_launch_ms_timed_region": round(shared_s[dom] / max(1, shared_n[dom]) * 1e3, 4),
+        "one_lane_ms_per_step": round(one_lane_ms, 3),
+        "algorithmic_bytes_per_launch": round(alg_per_launch),
+        "nodes_per_ray": [round(p[0], 2) for p in per_ray], "tris_per_ray": [round(p[1], 2) for p in per_ray],
+        "node_bytes": acc["node_bytes"], "tri_bytes": acc["tri_bytes"],
+        # whole job (SURVEY 8d): algorithmic bytes of all five stages per second of the timed region, and the
+        # compulsory lower bound (scene structures read once + film written once) the re-reads are measured against
+        "job_algorithmic_gbps": round(sum(sum(stage_bytes(s_, n_b, n_l, per_ray, acc["node_bytes"], acc["tri_bytes"])) for s_ in stats) / elapsed / 1e9, 2),
+        "compulsory_bytes_per_step": int(acc["n_nodes"] * (acc["node_bytes"] + 128) + acc["n_leaf_tris"] * acc["tri_bytes"]
+                                         + scene._nv * (12 + 12 + 8) + scene._nt * 12 + W * H * 5 * 4),
+        "stage_ms_per_step": {abi.STAGE_NAMES[k]: round(stage_s[k] / x_steps * 1e3, 3) for k in range(5)},
+        "stage_ms_per_step_timed_region": {abi.STAGE_NAMES[k]: round(shared_s[k] / args.steps * 1e3, 3) for k in range(5)}})
+    return r
+
+
+def secondary_c2(device, proj):
+    """C2 (Sponza-class interior, 1080p, 256 spp) timed briefly in the same run: the cache-resident counterpart of the headline."""
+    import torch
+    import kkdirect
+    scene, spp, label = make_workload("c2", 1.0)
+    ctx = kkdirect.Context(device=device, seed=1, projection_test=proj).upload(scene)
+    film = torch.zeros(ctx.height * ctx.width * 5, dtype=torch.float32, device="cuda")
+    for _ in range(2):
+        ctx.render_device(film.data_ptr(), spp)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st = [ctx.render_device(film.data_ptr(), spp) for _ in range(5)]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ctx.close()
+    return {"workload": label, "value": round(sum(s.samples for s in st) / dt / 1e6, 3), "unit": "Msamples/s", "steps": 5, "warmup": 2,
+            "ms_per_step": round(dt / 5 * 1e3, 3), "mrays_per_s": round(sum(s.rays_closest + s.rays_shadow for s in st) / dt / 1e6, 3)}
 
 
 def cpu_baseline(scene, n_b, n_l, W, H):

@@ -43,42 +43,69 @@ def chord_rays(n, center, radius, seed=0, mint=0.0):
     return rays
 
 
-def classify_mismatches(scene, rays, a, b):
-    """For rays whose primitive ids differ between two tracers, decide whether each one is a documented tie:
-      (1) edge/vertex tie: the ray passes within the single-precision resolution of the reference's projection test of
-          an edge of either reported triangle (barycentric distance < max(1e-5, 64 ulp * |coordinates| / shortest edge));
-      (2) equal-distance tie: both hits at the same t (coplanar / duplicate / crossing triangles);
-      (3) epsilon-band tie: one of the hits lies within 64x the ray's own adaptive epsilon of its origin -- a ray that
-          starts ON a surface, where the plane equation of the reference's TriAccel test (n_d - o.n)/(d.n) has cancelled
-          to noise and reports (or misses) the surface it starts on.
-    Returns the number of mismatches in none of these classes."""
+def explain_mismatches(scene, rays, a, b, any_hit=False):
+    """Every ray on which two tracers report different primitives is re-evaluated in float64 against the (at most two)
+    triangles in dispute and must be shown to be a TIE there -- no class is admitted on the word of the tracers' own t:
+      * edge / vertex tie: in float64 the ray passes a reported triangle's edge within the single-precision resolution of
+        the reference's projection test (barycentric distance <= bary_tol, see below);
+      * interval tie: the float64 hit distance of a disputed triangle lies within t_err of the ray's own (adaptive) mint
+        or of maxt -- this is what replaces the "epsilon band" of round 1: rays that start on a surface and meet it again
+        at exactly their epsilon;
+      * equal-distance tie: both triangles are decisively hit in float64 and their distances differ by <= the sum of
+        their t_err (coplanar / duplicate / crossing triangles).
+    t_err bounds the rounding of the reference's t = (n_d - o_u n_u - o_v n_v - o_k) / (d_u n_u + d_v n_v + d_k) (TriAccel,
+    SURVEY 9.1): 16 ulp of the largest term of the numerator over |denominator|; bary_tol = 64 ulp * coordinate scale /
+    shortest edge (>= 1e-5), plus the barycentric shift t_err causes.
+    Returns (n_mismatch, n_unexplained, classes) with classes = counts per tie class."""
     pos, idx, _, _ = scene.arrays()
-    bad = 0
-    for i in np.nonzero(a["prim"] != b["prim"])[0]:
-        ok = False
-        ta, tb = float(a["t"][i]), float(b["t"][i])
-        if np.isfinite(ta) and np.isfinite(tb) and abs(ta - tb) <= 1e-4 * max(abs(ta), 1e-6):
-            ok = True
+    pos = pos.astype(np.float64)
+    eps32 = 2.0 ** -24
+    classes = {"edge_vertex": 0, "interval": 0, "equal_distance": 0, "unexplained": 0}
+    mism = np.nonzero(a["prim"] != b["prim"])[0]
+    for i in mism:
         o = rays[i, 0:3].astype(np.float64); d = rays[i, 4:7].astype(np.float64)
-        mint = float(rays[i, 3])
-        if np.float32(mint) == np.float32(1e-4):
-            mint *= max(np.abs(o).max(), 1e-4)
-        if min(ta, tb) <= 64 * mint and mint > 0:
-            ok = True
+        mint = float(rays[i, 3]); maxt = float(rays[i, 7])
+        if np.float32(mint) == np.float32(1e-4):                     # skdtree.cpp:126-129 / :213-214
+            m = np.abs(rays[i, 0:3]).max()
+            mint = float(np.float32(mint) * np.float32(m if any_hit else max(m, np.float32(1e-4))))
+        verdicts = []
         for h in (a[i], b[i]):
             if h["prim"] == 0xFFFFFFFF:
                 continue
-            p0, p1, p2 = (pos[idx[h["prim"], k]].astype(np.float64) for k in range(3))
+            p0, p1, p2 = (pos[idx[h["prim"], k]] for k in range(3))
             e1, e2 = p1 - p0, p2 - p0
-            pv = np.cross(d, e2); det = e1 @ pv
-            if abs(det) < 1e-30:
-                ok = True; continue
-            tv = o - p0; u = (tv @ pv) / det; qv = np.cross(tv, e1); v = (d @ qv) / det
+            n = np.cross(e1, e2)
+            den = n @ d
+            if abs(den) < 1e-300:
+                verdicts.append(("marginal", "edge_vertex", 0.0, 0.0)); continue
+            t = (n @ (p0 - o)) / den
+            hp = o + t * d
+            # barycentrics of the exact hit point
+            area2 = n @ n
+            u = (np.cross(hp - p0, e2) @ n) / area2
+            v = (np.cross(e1, hp - p0) @ n) / area2
+            w = 1.0 - u - v
+            k = int(np.argmax(np.abs(n)))
+            num_terms = max(abs(n @ p0), *(abs(n[j] * o[j]) for j in range(3))) / abs(n[k])
+            t_err = 16 * eps32 * num_terms / max(abs(den / n[k]), 1e-300)
             scale = max(np.abs(p0).max(), np.abs(p1).max(), np.abs(p2).max(), np.abs(o).max())
             shortest = min(np.linalg.norm(e1), np.linalg.norm(e2), np.linalg.norm(p2 - p1))
-            tol = max(1e-5, 64 * 6e-8 * scale / max(shortest, 1e-30))
-            if min(u, v, 1 - u - v) < tol:
-                ok = True
-        if not ok:
-            bad += 1
-    return bad
+            bary_tol = max(1e-5, 64 * 6e-8 * scale / max(shortest, 1e-300)) + t_err * np.linalg.norm(d) / max(shortest, 1e-300)
+            mb = min(u, v, w)
+            if abs(mb) <= bary_tol:
+                verdicts.append(("marginal", "edge_vertex", t, t_err))
+            elif abs(t - mint) <= t_err or (np.isfinite(maxt) and abs(t - maxt) <= t_err):
+                verdicts.append(("marginal", "interval", t, t_err))
+            elif mb > 0 and mint < t < maxt:
+                verdicts.append(("hit", None, t, t_err))
+            else:
+                verdicts.append(("miss", None, t, t_err))
+        cls = None
+        marg = [v for v in verdicts if v[0] == "marginal"]
+        if marg:
+            cls = marg[0][1]
+        elif len(verdicts) == 2 and verdicts[0][0] == "hit" and verdicts[1][0] == "hit" and \
+                (any_hit or abs(verdicts[0][2] - verdicts[1][2]) <= verdicts[0][3] + verdicts[1][3]):
+            cls = "equal_distance"      # (occlusion queries may report any hit along the ray)
+        classes[cls or "unexplained"] += 1
+    return len(mism), classes["unexplained"], classes
