@@ -31,21 +31,21 @@
 MTS_NAMESPACE_BEGIN
 
 /* what the class keeps between render() and cancel(): the context of the render in flight (cancel() runs on another thread) */
-struct KKDGpuState { kkd_ctx *volatile ctx; KKDGpuState() : ctx(NULL) { } };
+struct KKDGpuState { kkd_multi *volatile ctx; KKDGpuState() : ctx(NULL) { } };
 
 static void kkdOnProgress(void *user, uint64_t done, uint64_t total) {
     static_cast<ProgressReporter *>(user)->update((size_t) (total ? done * 1000 / total : 1000));
 }
 
 /* SamplingIntegrator::cancel for the GPU render (src/librender/integrator.cpp:90-93) */
-static inline void kkdCancelOnGpu(KKDGpuState *gpu) { kkd_ctx *c = gpu->ctx; if (c) kkd_request_cancel(c); }
+static inline void kkdCancelOnGpu(KKDGpuState *gpu) { kkd_multi *c = gpu->ctx; if (c) kkd_multi_request_cancel(c); }
 
 /* The body of DirectIntegrator::render(); bsdfSamples / lightSamples / hideEmitters are the class's brdfSamplesNo /
  * lightSamplesNo / hideEmitters (src/integrators/kk/direct.cpp:17-21, 192-194). */
 static bool kkdRenderOnGpu(Scene *scene, RenderQueue *queue, const RenderJob *job, size_t bsdfSamples, size_t lightSamples,
                            bool hideEmittersFlag, KKDGpuState *gpu) {
     {
-        kkd_ctx *&m_ctx = const_cast<kkd_ctx *&>(gpu->ctx);
+        kkd_multi *&m_ctx = const_cast<kkd_multi *&>(gpu->ctx);
         /* ---- geometry: Scene::getMeshes() holds the TriMesh of every shape in addShape order, which is the order
          * ShapeKDTree numbers primitives in (src/librender/scene.cpp:558-591, src/librender/skdtree.cpp:49-70), so
          * global primitive id = first_prim + primIndex on both sides ---- */
@@ -171,15 +171,20 @@ static bool kkdRenderOnGpu(Scene *scene, RenderQueue *queue, const RenderJob *jo
         sd.envmap = env; sd.sensor = ks;
 
         /* ---- render ---- */
-        kkd_config cfg; memset(&cfg, 0, sizeof(cfg));
-        cfg.seed = 1;
-        m_ctx = kkd_create(&cfg);
-        if (!m_ctx) SLog(EError, "kkIntegrator: %s", kkd_last_error(NULL));          /* throws (src/librender/renderjob.cpp:111-115) */
-        if (kkd_scene_upload(m_ctx, &sd) != KKD_OK) { std::string msg = kkd_last_error(m_ctx); kkd_destroy(m_ctx); m_ctx = NULL; SLog(EError, "kkIntegrator: %s", msg.c_str()); }
+        /* every GPU of the node, image tiles dealt out among them (what the scheduler's workers are to the CPU path,
+         * src/librender/integrator.cpp:102-109); a single GPU is the same call with one device */
+        std::vector<int32_t> devices(std::max(1, kkd_device_count()));
+        for (size_t i = 0; i < devices.size(); ++i) devices[i] = (int32_t) i;
+        kkd_multi_config cfg; memset(&cfg, 0, sizeof(cfg));
+        cfg.n_devices = (uint32_t) devices.size(); cfg.devices = &devices[0]; cfg.split = KKD_SPLIT_TILE; cfg.seed = 1;
+        m_ctx = kkd_multi_create(&cfg);
+        if (!m_ctx) SLog(EError, "kkIntegrator: %s", kkd_multi_last_error(NULL));    /* throws (src/librender/renderjob.cpp:111-115) */
+        if (kkd_multi_scene_upload(m_ctx, &sd) != KKD_OK) { std::string msg = kkd_multi_last_error(m_ctx); kkd_multi_destroy(m_ctx); m_ctx = NULL; SLog(EError, "kkIntegrator: %s", msg.c_str()); }
+        SLog(EInfo, "kkIntegrator: rendering on %i GPU(s)", (int) kkd_multi_device_count(m_ctx));
 
         /* progress: ProgressReporter as BlockedRenderProcess does (src/librender/renderproc.cpp:146, 179) */
         ProgressReporter progress("Rendering", 1000, job);
-        kkd_set_progress_callback(m_ctx, &kkdOnProgress, &progress);
+        kkd_multi_set_progress_callback(m_ctx, &kkdOnProgress, &progress);
 
         kkd_render_params rp; memset(&rp, 0, sizeof(rp));
         rp.spp = (uint32_t) scene->getSampler()->getSampleCount();                   /* src/librender/integrator.cpp:103-104 */
@@ -187,7 +192,7 @@ static bool kkdRenderOnGpu(Scene *scene, RenderQueue *queue, const RenderJob *jo
         rp.block_size = scene->getBlockSize(); rp.tile_count = 1;
         ref<ImageBlock> block = new ImageBlock(Bitmap::ESpectrumAlphaWeight, film->getCropSize(), NULL);
         kkd_stats st;
-        const int rc = kkd_render(m_ctx, &rp, block->getBitmap()->getFloat32Data(), &st);
+        const int rc = kkd_multi_render(m_ctx, &rp, block->getBitmap()->getFloat32Data(), &st);
         if (rc == KKD_OK) {
             block->setOffset(film->getCropOffset());
             const_cast<Film *>(film)->put(block);                                    /* src/films/hdrfilm.cpp:391-393 */
@@ -195,10 +200,10 @@ static bool kkdRenderOnGpu(Scene *scene, RenderQueue *queue, const RenderJob *jo
             SLog(EInfo, "kkIntegrator (GPU): %.1f Msamples/s, %.1f Mrays/s, %.2f s", st.samples / st.seconds * 1e-6,
                 (st.rays_closest + st.rays_shadow) / st.seconds * 1e-6, st.seconds);
         } else if (rc != KKD_ERR_CANCELLED) {
-            std::string msg = kkd_last_error(m_ctx); kkd_destroy(m_ctx); m_ctx = NULL;
+            std::string msg = kkd_multi_last_error(m_ctx); kkd_multi_destroy(m_ctx); m_ctx = NULL;
             SLog(EError, "kkIntegrator: %s", msg.c_str());
         }
-        kkd_destroy(m_ctx); m_ctx = NULL;
+        kkd_multi_destroy(m_ctx); m_ctx = NULL;
         return rc == KKD_OK;                                                         /* false on cancel (src/librender/integrator.cpp:128) */
     }
 

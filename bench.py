@@ -117,12 +117,23 @@ def main():
     n_b = n_l = 1
     t0 = time.perf_counter()
     proj = args.leaf_test == "projection"
-    ctx = kkdirect.Context(device=local_rank, seed=1, max_samples_in_flight=args.batch, projection_test=proj).upload(scene)
+    # One process, several GPUs (python bench.py --gpus N without a launcher): the library's own multi-device path
+    # (kkd_multi_*: one host thread per device, tile gather over xGMI or RCCL reduce).  Under torch.distributed.run every
+    # rank is one process with one GPU and the films are reduced through torch (RCCL) below.
+    in_library = world == 1 and args.gpus > 1
+    if in_library:
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit("--gpus %d but %d devices visible" % (args.gpus, torch.cuda.device_count()))
+        ctx = kkdirect.MultiContext(list(range(args.gpus)), split=args.split, seed=1, max_samples_in_flight=args.batch, projection_test=proj).upload(scene)
+    else:
+        ctx = kkdirect.Context(device=local_rank, seed=1, max_samples_in_flight=args.batch, projection_test=proj).upload(scene)
     upload_s = time.perf_counter() - t0
     W, H = ctx.width, ctx.height
     film = torch.zeros(H * W * 5, dtype=torch.float32, device="cuda")
 
-    if args.split == "tile":
+    if in_library:
+        kw = dict(spp=spp * args.gpus)          # the library shards it; per-GPU work stays constant (weak scaling)
+    elif args.split == "tile":
         kw = dict(spp=spp * world, tile_index=rank, tile_count=world, sample_first=0)
     else:
         kw = dict(spp=spp, tile_index=0, tile_count=1, sample_first=rank * spp)
@@ -163,23 +174,27 @@ def main():
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         samples, rays = float(c[0].item()), float(c[1].item())
 
+    film_weight = float(film.view(-1, 5)[:, 4].sum().item()) if rank == 0 else 0.0
     out = None
     if rank == 0:
         roofline = None
-        if not args.no_extra_passes:
+        if not args.no_extra_passes and not in_library:
             roofline = measure_roofline(ctx, scene, args, kw, n_b, n_l, spp, film, stats, elapsed, local_rank, proj, W, H)
         cpu = None
-        if not args.no_cpu_baseline and world == 1 and not args.no_extra_passes:
+        if not args.no_cpu_baseline and world == 1 and not in_library and not args.no_extra_passes:
             cpu = cpu_baseline(scene, n_b, n_l, W, H)
         secondary = None
-        if world == 1 and args.workload == "c4" and args.integrator == "kk" and not (args.no_secondary or args.no_extra_passes or args.spp or args.scale != 1.0):
+        if world == 1 and not in_library and args.workload == "c4" and args.integrator == "kk" and not (args.no_secondary or args.no_extra_passes or args.spp or args.scale != 1.0):
             secondary = secondary_c2(local_rank, proj)
         out = {
             "metric": "Msamples/s (kk direct integrator)" if args.integrator == "kk" else "Msamples/s (%s plugin, not the headline metric)" % args.integrator, "value": round(samples / elapsed / 1e6, 3), "unit": "Msamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "n_gpus": args.gpus if in_library else world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "mrays_per_s": round(rays / elapsed / 1e6, 3),
-            "config": {"workload": label, "spp_total": kw["spp"] if args.split == "tile" else spp * world, "bsdfSamples": n_b, "lightSamples": n_l,
+            "config": {"workload": label, "spp_total": kw["spp"] if (args.split == "tile" or in_library) else spp * world,
+                       "multi_gpu": "in-library (kkd_multi, merge: %s)" % ctx.merge_path if in_library else ("one process per GPU, film reduce through torch.distributed (%s)" % backend if world > 1 else None),
+                       # weight channel of the merged film / samples of one step: 1 up to what the filter spills over the frame edge
+                       "film_weight_per_sample": round(film_weight / max(1.0, samples / args.steps), 5), "bsdfSamples": n_b, "lightSamples": n_l,
                        "integrator": args.integrator, "max_depth": args.max_depth if args.integrator == "path" else None,
                        "split": args.split, "backend": backend, "leaf_test": args.leaf_test, "triangles": int(scene._nt), "scene_upload_s": round(upload_s, 2)},
             "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary,

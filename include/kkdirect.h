@@ -185,10 +185,11 @@ typedef struct kkd_render_params {
     uint32_t bsdf_samples;     /* 'bsdfSamples'  (default 1)                                   */
     uint32_t light_samples;    /* 'lightSamples' (default 1)                                   */
     int32_t  hide_emitters;    /* 'hideEmitters' (default false)                               */
-    /* sharding: render only tiles t with t % tile_count == tile_index (tile mode), and only sample
+    /* sharding: render only the tiles of rank tile_index out of tile_count (tile mode), and only sample
      * indices [sample_first, sample_first+spp) of each pixel (sample-split mode).               */
     uint32_t block_size;       /* tile edge in pixels, 0 = 32 (scene.cpp:24)                   */
-    uint32_t tile_index, tile_count;  /* 0,1 (or 0,0) = all tiles                              */
+    uint32_t tile_index, tile_count;  /* 0,1 (or 0,0) = all tiles; else the tiles are dealt out round-robin along the Morton
+                                         curve of the tile grid and this call renders the share of rank tile_index */
     uint32_t sample_first;     /* first RNG sample index (0)                                   */
     /* which Li: KKD_INTEGRATOR_KK = the path of this library, DirectIntegrator::Li (src/integrators/kk/direct.cpp:50-178);
      * KKD_INTEGRATOR_DIRECT = its sibling on the same kernels, MIDirectIntegrator::Li of the stock 'direct' plugin
@@ -412,6 +413,62 @@ void kkd_request_cancel(kkd_ctx *ctx);
  * the last call of a finished render reports done == total.  fn == NULL removes the callback.  It must not call into ctx. */
 typedef void (*kkd_progress_fn)(void *user, uint64_t samples_done, uint64_t samples_total);
 int kkd_set_progress_callback(kkd_ctx *ctx, kkd_progress_fn fn, void *user);
+
+/* ---- several GPUs of one node behind one handle ---------------------------------------------------------------
+ * What the reference does with its scheduler -- every worker renders blocks (src/librender/renderproc.cpp:68-86),
+ * BlockedRenderProcess::processResult adds each into the film (src/librender/renderproc.cpp:142-149 -> Film::put,
+ * src/films/hdrfilm.cpp:391-393); work units come from BlockedImageProcess (src/librender/imageproc.cpp:28-78) -- for the
+ * GPUs of one node: one context per listed device, the scene flattened once and replicated, one host thread per device
+ * while rendering, no exchange before the frame is done.
+ *   KKD_SPLIT_TILE    the image tiles are dealt out to the devices round-robin along the Morton curve of the tile grid;
+ *                     each device's tiles travel to the first device (the root) with their filter borders in one peer
+ *                     copy and are added into the root's film there;
+ *   KKD_SPLIT_SAMPLE  every device renders the whole frame with spp / n_devices samples per pixel (disjoint sample
+ *                     indices); the films are summed to the root by one RCCL reduce (librccl is loaded at run time; if it
+ *                     is absent, or a device is listed twice, the films are copied to the root and added there).
+ * The sample stream is keyed by pixel and sample index, so the film does not depend on the number of devices (up to the
+ * order of float additions).  A caller's own tile_index / tile_count / sample_first (a job spread over several nodes or
+ * processes) are refined, not replaced. */
+#define KKD_SPLIT_TILE   0u
+#define KKD_SPLIT_SAMPLE 1u
+typedef struct kkd_multi_config {
+    uint32_t n_devices;        /* 1..64                                                          */
+    uint32_t split;            /* KKD_SPLIT_*                                                    */
+    const int32_t *devices;    /* n_devices HIP device ordinals; devices[0] is the root           */
+    uint32_t flags;            /* KKD_FLAG_*, as kkd_config                                      */
+    uint32_t reserved;
+    uint64_t seed;
+    uint64_t max_samples_in_flight;   /* per device, 0 = library default                         */
+} kkd_multi_config;
+typedef struct kkd_multi kkd_multi;
+
+/* One context per listed device: replaces the per-worker state of BlockedRenderProcess / BlockRenderer
+ * (src/librender/renderproc.cpp:26-66) and the worker set-up of src/mitsuba/mitsuba.cpp:260-264.  NULL on failure
+ * (kkd_last_error(NULL) / kkd_multi_last_error(NULL) has the text). */
+kkd_multi *kkd_multi_create(const kkd_multi_config *cfg);
+/* kkd_scene_upload for every device: one host-side build (Scene::preprocess -> ShapeKDTree::build,
+ * src/librender/skdtree.cpp:68-110), uploads side by side. */
+int kkd_multi_scene_upload(kkd_multi *m, const kkd_scene_desc *scene);
+/* kkd_render / kkd_render_device over all devices: SamplingIntegrator::render (src/librender/integrator.cpp:95-129) with
+ * the film merged as BlockedRenderProcess::processResult does (src/librender/renderproc.cpp:142-149).  out_film: host
+ * memory; dev_film: device memory on devices[0].  stats: counters summed over the devices, seconds = host wall clock of the
+ * job including the merge; stage_seconds summed over the devices. */
+int kkd_multi_render(kkd_multi *m, const kkd_render_params *params, float *out_film, kkd_stats *stats);
+/* same (src/librender/integrator.cpp:95-129, src/librender/renderproc.cpp:142-149), merged film left in device memory on devices[0] */
+int kkd_multi_render_device(kkd_multi *m, const kkd_render_params *params, void *dev_film, kkd_stats *stats);
+/* SamplingIntegrator::cancel (src/librender/integrator.cpp:90-93) for every device; thread-safe. */
+void kkd_multi_request_cancel(kkd_multi *m);
+/* kkd_set_progress_callback for the whole job (ProgressReporter::update per finished block,
+ * src/librender/renderproc.cpp:142-149): fn receives the work items finished on all devices and their total; it is called from the devices' host
+ * threads, one call at a time. */
+int kkd_multi_set_progress_callback(kkd_multi *m, kkd_progress_fn fn, void *user);
+/* how the last render merged its films: "single", "tile-gather", "rccl-reduce" or "copy-add" (measurement / tests; the
+ * reference logs its scheduler set-up the same way, src/librender/integrator.cpp:102-109) */
+const char *kkd_multi_merge_path(kkd_multi *m);
+uint32_t kkd_multi_device_count(kkd_multi *m);   /* contexts behind the handle (src/librender/integrator.cpp:102: getCoreCount) */
+const char *kkd_multi_last_error(kkd_multi *m);  /* as kkd_last_error (src/librender/renderjob.cpp:111-115) */
+/* releases every context (the reference tears its workers down in Scheduler::staticShutdown, src/mitsuba/mitsuba.cpp:436) */
+void kkd_multi_destroy(kkd_multi *m);
 
 /* Mitsuba convention is Log(EError, ...) -> exception (src/librender/renderjob.cpp:111-115); here the
  * text is kept per context.  Never NULL.  ctx == NULL returns the last error of kkd_create. */

@@ -8,7 +8,9 @@
  * context are walked in batches of camera samples, each batch being five kernel launches on one stream.
  */
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <cstdio>
 #include <cstdlib>
@@ -78,7 +80,7 @@ struct kkd_ctx {
     std::string err;
     std::atomic<int> cancel{0};
     bool haveScene = false;
-    HostScene hs;
+    BVH4::Info accelInfo{};
     DScene ds{};
     /* scene buffers */
     DevBuf nodes, wideNodes, tris, projTris, positions, normals, texcoords, indices, shapes, materials, emitters, emitterCdf, emitterGuide, areaGuide, areaCdf, rtTables,
@@ -93,6 +95,8 @@ struct kkd_ctx {
     kkd_progress_fn progressFn = nullptr; void *progressUser = nullptr;
     /* set up by kkd_create so that kkd_trace_device_noalloc never allocates: this device's scratch array, two timing
      * events, a pinned host copy of the counter shards */
+    /* tile sharding: this context's tiles (Morton round-robin), cached for the last (grid, index, count) */
+    DevBuf tileList; std::vector<uint32_t> tileListHost; uint32_t tileKey[4] = { 0, 0, 0, 0 };
     void *noallocScratch = nullptr;
     hipEvent_t traceEv[2] = { nullptr, nullptr };
     DeviceCounters *hostShards = nullptr;
@@ -173,7 +177,7 @@ void kkd_destroy(kkd_ctx *ctx) {
                       &ctx->emitters, &ctx->emitterCdf, &ctx->areaCdf, &ctx->rtTables, &ctx->envTexels, &ctx->envCdfRows, &ctx->envCdfCols,
                       &ctx->envRowWeights, &ctx->contRecs, &ctx->contStacks, &ctx->contCount, &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->shadowRays,
                       &ctx->occluded, &ctx->lrec, &ctx->film, &ctx->counters, &ctx->apiRays, &ctx->apiHits,
-                      &ctx->envGuideRows, &ctx->envGuideCols, &ctx->emitterGuide, &ctx->areaGuide, &ctx->pathAlive, &ctx->pBsdfRays, &ctx->pBrec, &ctx->pRefN, &ctx->pShadowRays, &ctx->pLrec, &ctx->pSampleIdx };
+                      &ctx->envGuideRows, &ctx->envGuideCols, &ctx->emitterGuide, &ctx->areaGuide, &ctx->pathAlive, &ctx->pBsdfRays, &ctx->pBrec, &ctx->pRefN, &ctx->pShadowRays, &ctx->pLrec, &ctx->pSampleIdx, &ctx->tileList };
     for (DevBuf *b : all) b->release();
     for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->doneEvents) hipEventDestroy(ev);
@@ -184,15 +188,18 @@ void kkd_destroy(kkd_ctx *ctx) {
     delete ctx;
 }
 
-int kkd_scene_upload(kkd_ctx *ctx, const kkd_scene_desc *sd) {
-    if (!ctx) return KKD_ERR_INVALID;
-    ctx->haveScene = false;
+/* host half of kkd_scene_upload: validate + flatten + build (once per scene, whatever the number of devices) */
+static int buildHostScene(kkd_ctx *ctx, const kkd_scene_desc *sd, HostScene &hs) {
     int code = KKD_ERR_INVALID;
-    if (!flattenScene(sd, ctx->hs, ctx->err, &code)) return code;
-    HostScene &hs = ctx->hs;
+    if (!flattenScene(sd, hs, ctx->err, &code)) return code;
     /* the kernels index their stack without a bound check: the builder's worst-case occupancy must fit */
     if (hs.bvh.info.maxStack > kMaxTraversalStack) return fail(ctx, KKD_ERR_UNSUPPORTED, "acceleration structure deeper than the traversal stack");
     for (LeafTri &t : hs.bvh.tris) { const int32_t e = hs.shapes[t.shape].emitter; t.emitter = e >= 0 ? (uint32_t)e + 1u : 0u; }
+    return KKD_OK;
+}
+
+/* device half: copy the flattened scene `hs` (this context's own, or another context's: multi-device renders build once) */
+static int uploadHostScene(kkd_ctx *ctx, const HostScene &hs, const kkd_scene_desc *sd) {
     KKD_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
 #define UP(buf, ptr, n) if ((rc = upload(ctx, ctx->buf, ptr, n)) != KKD_OK) return rc;
@@ -240,11 +247,20 @@ int kkd_scene_upload(kkd_ctx *ctx, const kkd_scene_desc *sd) {
     d.env.cdfCols = (const float *)ctx->envCdfCols.p; d.env.rowWeights = (const float *)ctx->envRowWeights.p;
     d.env.guideRows = (const uint32_t *)ctx->envGuideRows.p; d.env.guideCols = (const uint32_t *)ctx->envGuideCols.p;
     d.sensor = hs.sensor; d.filter = hs.filter;
-    /* host copies that are only needed for the upload */
-    std::vector<uint16_t>().swap(hs.envTexels); std::vector<float>().swap(hs.envCdfCols);
+    ctx->accelInfo = hs.bvh.info;
+    ctx->tileKey[3] = 0;            /* a new film / tile grid: the cached tile list is stale */
     ctx->haveScene = true;
     ctx->err.clear();
     return KKD_OK;
+}
+
+int kkd_scene_upload(kkd_ctx *ctx, const kkd_scene_desc *sd) {
+    if (!ctx) return KKD_ERR_INVALID;
+    ctx->haveScene = false;
+    HostScene hs;                    /* host copies are only needed for the upload */
+    int rc = buildHostScene(ctx, sd, hs);
+    if (rc == KKD_OK) rc = uploadHostScene(ctx, hs, sd);
+    return rc;
 }
 
 int kkd_accel_info(kkd_ctx *ctx, uint32_t *node_bytes, uint32_t *tri_bytes, uint64_t *n_nodes, uint64_t *n_leaf_tris) {
@@ -252,8 +268,8 @@ int kkd_accel_info(kkd_ctx *ctx, uint32_t *node_bytes, uint32_t *tri_bytes, uint
     if (!ctx->haveScene) return fail(ctx, KKD_ERR_INVALID, "no scene uploaded");
     if (node_bytes) *node_bytes = (uint32_t)sizeof(Node4);
     if (tri_bytes) *tri_bytes = (uint32_t)sizeof(LeafTri);
-    if (n_nodes) *n_nodes = ctx->hs.bvh.info.nNodes;
-    if (n_leaf_tris) *n_leaf_tris = ctx->hs.bvh.info.nLeafTris;
+    if (n_nodes) *n_nodes = ctx->accelInfo.nNodes;
+    if (n_leaf_tris) *n_leaf_tris = ctx->accelInfo.nLeafTris;
     return KKD_OK;
 }
 
@@ -398,6 +414,27 @@ int kkd_trace_counted(kkd_ctx *ctx, const float *rays, uint64_t n, int any_hit, 
 /* ---- render ---- */
 static uint32_t pow2ceil(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
 
+/* Tile -> rank assignment of the tile-sharded mode: the tiles of the nbx x nby grid are walked along their
+ * Morton curve and dealt out round-robin, tile k of that walk to rank k % count.  Every rank's tiles are spread evenly over
+ * the image (lights and dense geometry cluster spatially), consecutive tiles of a rank stay close to each other, and N = 2
+ * ... 8 never degenerate into stripes the way "row-major index % N" does when N divides the row length.  Replaces the
+ * work queue of BlockedImageProcess (reference src/librender/imageproc.cpp:28-78), which balances dynamically. */
+static uint32_t part1by1(uint32_t x) { x &= 0xffffu; x = (x | (x << 8)) & 0x00ff00ffu; x = (x | (x << 4)) & 0x0f0f0f0fu; x = (x | (x << 2)) & 0x33333333u; return (x | (x << 1)) & 0x55555555u; }
+/* out: the tiles of rank `index`; rankOf (optional): the rank of every tile of the grid, appended to out (the film merge
+ * uses it to send a pixel that several of a rank's tile regions cover only once) */
+static void tilesOfRank(uint32_t nbx, uint32_t nby, uint32_t index, uint32_t count, std::vector<uint32_t> &out, bool appendRankOf = false) {
+    std::vector<std::pair<uint32_t, uint32_t>> order; order.reserve((size_t)nbx * nby);
+    for (uint32_t ty = 0; ty < nby; ++ty) for (uint32_t tx = 0; tx < nbx; ++tx) order.emplace_back(part1by1(tx) | (part1by1(ty) << 1), ty * nbx + tx);
+    std::sort(order.begin(), order.end());
+    out.clear();
+    for (size_t k = index; k < order.size(); k += count) out.push_back(order[k].second);
+    if (appendRankOf) {
+        const size_t base = out.size();
+        out.resize(base + order.size());
+        for (size_t k = 0; k < order.size(); ++k) out[base + order[k].second] = (uint32_t)(k % count);
+    }
+}
+
 static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm, kkd_stats *stats) {
     if (!ctx->haveScene) return fail(ctx, KKD_ERR_INVALID, "no scene uploaded");
     if (!rp) return fail(ctx, KKD_ERR_INVALID, "render params are NULL");
@@ -424,7 +461,19 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     const int W = ctx->ds.sensor.cropW, H = ctx->ds.sensor.cropH;
     const int edge = ctx->ds.sensor.hqEdges ? ctx->ds.filter.border : 0;   /* Film::hasHighQualityEdges (renderproc.cpp:163-171) */
     const uint32_t nbx = (W + 2 * edge + bs - 1) / bs, nby = (H + 2 * edge + bs - 1) / bs, nTiles = nbx * nby;
+    if (nbx > 0xffffu || nby > 0xffffu) return fail(ctx, KKD_ERR_UNSUPPORTED, "more than 65535 tiles along one axis");
     const uint32_t nTilesMine = tileIndex < nTiles ? (nTiles - tileIndex + tileCount - 1) / tileCount : 0;
+    if (tileCount > 1 && nTilesMine > 0) {
+        const uint32_t key[4] = { nbx, nby, tileIndex, tileCount };
+        if (std::memcmp(key, ctx->tileKey, sizeof(key)) != 0 || !ctx->tileList.p) {
+            tilesOfRank(nbx, nby, tileIndex, tileCount, ctx->tileListHost, true);      /* device copy: [my tiles | rank of every tile] */
+            int rcUp = upload(ctx, ctx->tileList, ctx->tileListHost.data(), ctx->tileListHost.size());
+            ctx->tileListHost.resize(nTilesMine);
+            if (rcUp != KKD_OK) return rcUp;
+            KKD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            std::memcpy(ctx->tileKey, key, sizeof(key));
+        }
+    }
     const uint32_t g = std::min(64u, pow2ceil(rp->spp)), chunks = (rp->spp + g - 1) / g;
     uint32_t gShift = 0; while ((1u << gShift) < g) ++gShift;
     const uint64_t total = (uint64_t)nTilesMine * bs * bs * chunks * g;
@@ -510,6 +559,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     bp.edge = edge;
     bp.bs = bs; bp.bsPow2 = (bs & (bs - 1)) == 0; bp.nbx = nbx; bp.nby = nby;
     bp.tileIndex = tileIndex; bp.tileCount = tileCount; bp.nTilesMine = nTilesMine; bp.W = W; bp.H = H;
+    bp.tileList = (tileCount > 1 && nTilesMine > 0) ? (const uint32_t *)ctx->tileList.p : nullptr;
 #ifdef KKD_ABLATION   /* ablation builds only (scripts/ab*.sh): a release library never reads result-changing switches */
     { const char *dbg = getenv("KKD_DEBUG"); bp.debug = dbg ? (uint32_t)atoi(dbg) : 0u; }
 #endif
@@ -695,6 +745,311 @@ int kkd_render(kkd_ctx *ctx, const kkd_render_params *params, float *out_film, k
     hipError_t e = hipMemcpy(out_film, ctx->film.p, bytes, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(ctx, KKD_ERR_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e));
     return rc;
+}
+
+} /* extern "C" */
+
+/* ==== multi-device rendering inside the library =============================================================
+ * One context per device, the scene flattened once and replicated, one host thread per device while rendering, no exchange
+ * until the frame is done.  Replaces, for one node, what the reference does with its scheduler: workers render blocks
+ * (src/librender/renderproc.cpp:68-86) and BlockedRenderProcess::processResult adds every block into the film under a
+ * mutex (renderproc.cpp:142-149 -> Film::put, src/films/hdrfilm.cpp:391-393).
+ *   tile mode:    rank r renders the tiles dealt to it (Morton round-robin, tilesOfRank) with their filter borders; its tiles
+ *                 are packed, moved to the root device by ONE peer copy (hipMemcpyPeerAsync over xGMI: film size / N plus
+ *                 borders per rank, not a whole film) and added into the root film there -- Film::put(block) per tile;
+ *   sample mode:  every rank renders the whole frame with its share of the samples; the films are summed by ONE
+ *                 ncclReduce (RCCL, loaded at run time) to the root.  Without RCCL, or with one device listed twice (the
+ *                 one-GPU rehearsal of the tests), the films are copied to the root and added there. */
+#include <dlfcn.h>
+#include <thread>
+
+namespace {
+/* the few RCCL entry points used, bound at run time so that libkkdirect.so loads on machines without librccl */
+struct Rccl {
+    typedef void *Comm;
+    int (*CommInitAll)(Comm *, int, const int *) = nullptr;
+    int (*CommDestroy)(Comm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Reduce)(const void *, void *, size_t, int /*ncclDataType_t*/, int /*ncclRedOp_t*/, int, Comm, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    void *lib = nullptr;
+    static constexpr int kFloat = 7 /* ncclFloat32 */, kSum = 0 /* ncclSum */;
+    bool load() {
+        if (lib) return true;
+        for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) { lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+        if (!lib) return false;
+        CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll"); CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart"); GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
+        Reduce = (decltype(Reduce))dlsym(lib, "ncclReduce"); GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Reduce) { dlclose(lib); lib = nullptr; return false; }
+        return true;
+    }
+};
+} /* namespace */
+
+struct kkd_multi {
+    std::vector<kkd_ctx *> ctx;          /* ctx[0] is the root: its device receives the merged film */
+    uint32_t split = KKD_SPLIT_TILE;
+    std::string err;
+    bool haveScene = false;
+    std::vector<DevBuf> packed;          /* per rank, on its device: its tiles, packed (tile mode) */
+    std::vector<DevBuf> staging;         /* per rank, on the root device: what the rank sent */
+    std::vector<DevBuf> rankTiles;       /* per rank, on the root device: the rank's tile list */
+    DevBuf rootFilm;                     /* root film of kkd_multi_render (host output) */
+    Rccl rccl; std::vector<Rccl::Comm> comms; bool distinct = false;
+    std::string mergePath;               /* "single", "tile-gather", "rccl-reduce", "copy-add" (what the last render used) */
+    /* progress of the whole job: the per-device reports are summed under a mutex and passed on */
+    kkd_progress_fn progressFn = nullptr; void *progressUser = nullptr;
+    struct RankProgress { kkd_multi *m; uint32_t rank; };
+    std::vector<RankProgress> rankProgress; std::vector<uint64_t> done, total; std::mutex progressMutex;
+    static void onRankProgress(void *user, uint64_t d, uint64_t t) {
+        RankProgress *rp = (RankProgress *)user; kkd_multi *m = rp->m;
+        std::lock_guard<std::mutex> lock(m->progressMutex);
+        m->done[rp->rank] = d; m->total[rp->rank] = t;
+        uint64_t sd = 0, stt = 0;
+        for (size_t r = 0; r < m->done.size(); ++r) { sd += m->done[r]; stt += m->total[r]; }
+        if (m->progressFn) m->progressFn(m->progressUser, sd, stt);
+    }
+};
+
+static int mfail(kkd_multi *m, int code, const std::string &msg) { m->err = msg; return code; }
+
+extern "C" {
+
+kkd_multi *kkd_multi_create(const kkd_multi_config *cfg) {
+    if (!cfg || cfg->n_devices == 0 || cfg->n_devices > 64 || (!cfg->devices && cfg->n_devices > 0) || cfg->split > KKD_SPLIT_SAMPLE) {
+        g_globalError = "kkd_multi_create: bad configuration (1..64 devices, split = KKD_SPLIT_TILE | KKD_SPLIT_SAMPLE)"; return nullptr;
+    }
+    kkd_multi *m = new kkd_multi();
+    m->split = cfg->split;
+    for (uint32_t r = 0; r < cfg->n_devices; ++r) {
+        kkd_config c{}; c.device = cfg->devices[r]; c.flags = cfg->flags; c.seed = cfg->seed; c.max_samples_in_flight = cfg->max_samples_in_flight;
+        kkd_ctx *x = kkd_create(&c);
+        if (!x) { kkd_multi_destroy(m); return nullptr; }       /* g_globalError holds the reason */
+        m->ctx.push_back(x);
+    }
+    const size_t n = m->ctx.size();
+    m->packed.resize(n); m->staging.resize(n); m->rankTiles.resize(n);
+    m->distinct = true;
+    for (size_t a = 0; a < n; ++a) for (size_t b = a + 1; b < n; ++b) if (m->ctx[a]->device == m->ctx[b]->device) m->distinct = false;
+    if (m->distinct && n > 1) {           /* direct xGMI copies between the root and every other device, where the platform allows them */
+        for (size_t r = 1; r < n; ++r) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, m->ctx[0]->device, m->ctx[r]->device) == hipSuccess && can) { hipSetDevice(m->ctx[0]->device); (void)hipDeviceEnablePeerAccess(m->ctx[r]->device, 0); }
+            if (hipDeviceCanAccessPeer(&can, m->ctx[r]->device, m->ctx[0]->device) == hipSuccess && can) { hipSetDevice(m->ctx[r]->device); (void)hipDeviceEnablePeerAccess(m->ctx[0]->device, 0); }
+        }
+        (void)hipGetLastError();          /* "already enabled" is not an error */
+    }
+    return m;
+}
+
+void kkd_multi_destroy(kkd_multi *m) {
+    if (!m) return;
+    for (Rccl::Comm c : m->comms) if (c && m->rccl.CommDestroy) m->rccl.CommDestroy(c);
+    for (size_t r = 0; r < m->ctx.size(); ++r) {
+        if (!m->ctx[r]) continue;
+        hipSetDevice(m->ctx[r]->device);
+        if (r < m->packed.size()) m->packed[r].release();
+    }
+    if (!m->ctx.empty() && m->ctx[0]) {
+        hipSetDevice(m->ctx[0]->device);
+        for (DevBuf &b : m->staging) b.release();
+        for (DevBuf &b : m->rankTiles) b.release();
+        m->rootFilm.release();
+    }
+    for (kkd_ctx *x : m->ctx) kkd_destroy(x);
+    delete m;
+}
+
+int kkd_multi_set_progress_callback(kkd_multi *m, kkd_progress_fn fn, void *user) {
+    if (!m) return KKD_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(m->progressMutex);
+    m->progressFn = fn; m->progressUser = user;
+    const size_t n = m->ctx.size();
+    m->rankProgress.resize(n); m->done.assign(n, 0); m->total.assign(n, 0);
+    for (size_t r = 0; r < n; ++r) {
+        m->rankProgress[r] = { m, (uint32_t)r };
+        kkd_set_progress_callback(m->ctx[r], fn ? &kkd_multi::onRankProgress : nullptr, &m->rankProgress[r]);
+    }
+    return KKD_OK;
+}
+
+const char *kkd_multi_last_error(kkd_multi *m) { return m ? m->err.c_str() : g_globalError.c_str(); }
+void kkd_multi_request_cancel(kkd_multi *m) { if (m) for (kkd_ctx *x : m->ctx) kkd_request_cancel(x); }
+uint32_t kkd_multi_device_count(kkd_multi *m) { return m ? (uint32_t)m->ctx.size() : 0u; }
+const char *kkd_multi_merge_path(kkd_multi *m) { return m ? m->mergePath.c_str() : ""; }
+
+int kkd_multi_scene_upload(kkd_multi *m, const kkd_scene_desc *sd) {
+    if (!m) return KKD_ERR_INVALID;
+    m->haveScene = false;
+    HostScene hs;
+    int rc = buildHostScene(m->ctx[0], sd, hs);                  /* the BVH and the tables are built ONCE ... */
+    if (rc != KKD_OK) return mfail(m, rc, m->ctx[0]->err);
+    std::vector<int> rcs(m->ctx.size(), KKD_OK);
+    std::vector<std::thread> th;
+    for (size_t r = 0; r < m->ctx.size(); ++r)                   /* ... and copied to every device side by side */
+        th.emplace_back([&, r] { m->ctx[r]->haveScene = false; rcs[r] = uploadHostScene(m->ctx[r], hs, sd); });
+    for (std::thread &t : th) t.join();
+    for (size_t r = 0; r < m->ctx.size(); ++r) if (rcs[r] != KKD_OK) return mfail(m, rcs[r], "device " + std::to_string(m->ctx[r]->device) + ": " + m->ctx[r]->err);
+    m->haveScene = true; m->err.clear();
+    return KKD_OK;
+}
+
+static int multiRender(kkd_multi *m, const kkd_render_params *rp, float *rootDevFilm, kkd_stats *stats) {
+    if (!m->haveScene) return mfail(m, KKD_ERR_INVALID, "no scene uploaded");
+    if (!rp) return mfail(m, KKD_ERR_INVALID, "render params are NULL");
+    const uint32_t n = (uint32_t)m->ctx.size();
+    kkd_ctx *root = m->ctx[0];
+    const int W = root->ds.sensor.cropW, H = root->ds.sensor.cropH;
+    const size_t filmFloats = (size_t)W * H * 5;
+    if (m->split == KKD_SPLIT_SAMPLE && rp->spp < n) return mfail(m, KKD_ERR_INVALID, "sample-split mode needs spp >= number of devices");
+    /* the caller's own shard (tile_index / tile_count / sample_first of a larger job) is refined, not replaced */
+    const uint32_t outerCount = rp->tile_count ? rp->tile_count : 1, outerIndex = rp->tile_count ? rp->tile_index : 0;
+    std::vector<kkd_render_params> prm(n, *rp);
+    uint32_t sampleAt = rp->sample_first;
+    for (uint32_t r = 0; r < n; ++r) {
+        if (m->split == KKD_SPLIT_TILE) { prm[r].tile_count = outerCount * n; prm[r].tile_index = outerIndex * n + r; }
+        else { prm[r].spp = rp->spp / n + (r < rp->spp % n ? 1u : 0u); prm[r].sample_first = sampleAt; sampleAt += prm[r].spp; }
+    }
+    std::vector<kkd_stats> st(n);
+    std::vector<int> rcs(n, KKD_OK);
+    std::vector<uint32_t> nTilesOf(n, 0);
+    const uint32_t bs = rp->block_size ? rp->block_size : 32;
+    const int border = root->ds.filter.border, edge = root->ds.sensor.hqEdges ? border : 0;
+    TileGrid grid; grid.bs = bs; grid.nbx = (uint32_t)((W + 2 * edge + (int)bs - 1) / (int)bs); grid.nby = (uint32_t)((H + 2 * edge + (int)bs - 1) / (int)bs);
+    grid.border = border; grid.edge = edge; grid.W = W; grid.H = H; grid.rankOf = nullptr; grid.myRank = 0;
+    const size_t perTile = (size_t)(bs + 2 * border) * (bs + 2 * border) * 5;
+    const bool gather = m->split == KKD_SPLIT_TILE && n > 1;
+    auto worker = [&](uint32_t r) {
+        kkd_ctx *x = m->ctx[r];
+        rcs[r] = renderImpl(x, &prm[r], r == 0 ? rootDevFilm : nullptr, &st[r]);      /* ranks > 0 render into their own film buffer */
+        if (rcs[r] != KKD_OK || r == 0 || !gather) return;
+        /* tile mode: pack this rank's tiles (with borders) and send them to the root device in one copy */
+        const uint32_t nt = (uint32_t)x->tileListHost.size();
+        nTilesOf[r] = nt;
+        if (nt == 0) return;
+        hipError_t e = m->packed[r].ensure(nt * perTile * sizeof(float));
+        TileGrid mine = grid; mine.rankOf = (const uint32_t *)x->tileList.p + nt; mine.myRank = prm[r].tile_index;
+        if (e == hipSuccess) { launchPackTiles(x->stream, (const float *)x->film.p, (float *)m->packed[r].p, (const uint32_t *)x->tileList.p, nt, mine); e = hipGetLastError(); }
+        if (e == hipSuccess) e = x->device == root->device ? hipMemcpyAsync(m->staging[r].p, m->packed[r].p, nt * perTile * sizeof(float), hipMemcpyDeviceToDevice, x->stream)
+                                                           : hipMemcpyPeerAsync(m->staging[r].p, root->device, m->packed[r].p, x->device, nt * perTile * sizeof(float), x->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(x->stream);
+        if (e != hipSuccess) { x->err = std::string("tile gather: ") + hipGetErrorString(e); rcs[r] = KKD_ERR_DEVICE; }
+    };
+    if (gather) {
+        /* staging buffers and the ranks' tile lists on the root device, sized before the workers start (the lists are a
+         * function of the grid alone) */
+        hipSetDevice(root->device);
+        const uint32_t nby = grid.nby;
+        if (grid.nbx > 0xffffu || nby > 0xffffu) return mfail(m, KKD_ERR_UNSUPPORTED, "more than 65535 tiles along one axis");
+        std::vector<uint32_t> list;
+        for (uint32_t r = 1; r < n; ++r) {
+            tilesOfRank(grid.nbx, nby, prm[r].tile_index, prm[r].tile_count, list);
+            hipError_t e = m->staging[r].ensure(std::max<size_t>(16, list.size() * perTile * sizeof(float)));
+            if (e == hipSuccess) e = m->rankTiles[r].ensure(std::max<size_t>(16, list.size() * sizeof(uint32_t)));
+            if (e == hipSuccess && !list.empty()) e = hipMemcpy(m->rankTiles[r].p, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (e != hipSuccess) return mfail(m, e == hipErrorOutOfMemory ? KKD_ERR_NOMEM : KKD_ERR_DEVICE, std::string("tile gather buffers: ") + hipGetErrorString(e));
+        }
+    }
+    if (m->progressFn) {   /* every rank's total is known only once it reports: start from "nothing done of nothing" */
+        std::lock_guard<std::mutex> lock(m->progressMutex);
+        m->done.assign(n, 0); m->total.assign(n, 0);
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (uint32_t r = 1; r < n; ++r) th.emplace_back(worker, r);
+    worker(0);
+    for (std::thread &t : th) t.join();
+    int rc = KKD_OK;
+    for (uint32_t r = 0; r < n; ++r) if (rcs[r] != KKD_OK && rc == KKD_OK) { rc = rcs[r]; m->err = "device " + std::to_string(m->ctx[r]->device) + ": " + m->ctx[r]->err; }
+    if (rc != KKD_OK) return rc;
+
+    /* ---- film merge on the root device ---- */
+    hipSetDevice(root->device);
+    hipError_t e = hipSuccess;
+    m->mergePath = "single";
+    if (gather) {
+        m->mergePath = "tile-gather";
+        for (uint32_t r = 1; r < n && e == hipSuccess; ++r) {
+            launchUnpackAddTiles(root->stream, rootDevFilm, (const float *)m->staging[r].p, (const uint32_t *)m->rankTiles[r].p, nTilesOf[r], grid);
+            e = hipGetLastError();
+        }
+    } else if (m->split == KKD_SPLIT_SAMPLE) {
+        bool reduced = false;
+        if (m->distinct && m->rccl.load()) {
+            /* one communicator per device, created on first use; a single-process group call issues the per-device halves */
+            if (m->comms.empty()) {
+                std::vector<int> devs; for (kkd_ctx *x : m->ctx) devs.push_back(x->device);
+                m->comms.assign(n, nullptr);
+                const int r0 = m->rccl.CommInitAll(m->comms.data(), (int)n, devs.data());
+                if (r0 != 0) { m->comms.clear(); m->err = std::string("ncclCommInitAll: ") + (m->rccl.GetErrorString ? m->rccl.GetErrorString(r0) : "failed"); }
+            }
+            if (!m->comms.empty()) {
+                int r1 = m->rccl.GroupStart();
+                for (uint32_t r = 0; r < n && r1 == 0; ++r) {
+                    const float *src = r == 0 ? rootDevFilm : (const float *)m->ctx[r]->film.p;
+                    r1 = m->rccl.Reduce(src, r == 0 ? rootDevFilm : (float *)m->ctx[r]->film.p, filmFloats, Rccl::kFloat, Rccl::kSum, 0, m->comms[r], m->ctx[r]->stream);
+                }
+                const int r2 = m->rccl.GroupEnd();
+                if (r1 == 0 && r2 == 0) {
+                    for (uint32_t r = 0; r < n && e == hipSuccess; ++r) { hipSetDevice(m->ctx[r]->device); e = hipStreamSynchronize(m->ctx[r]->stream); }
+                    hipSetDevice(root->device);
+                    reduced = e == hipSuccess; if (reduced) m->mergePath = "rccl-reduce";
+                } else return mfail(m, KKD_ERR_DEVICE, std::string("ncclReduce: ") + (m->rccl.GetErrorString ? m->rccl.GetErrorString(r1 ? r1 : r2) : "failed"));
+            }
+        }
+        if (!reduced && n > 1 && e == hipSuccess) {
+            m->mergePath = "copy-add";
+            for (uint32_t r = 1; r < n && e == hipSuccess; ++r) {
+                kkd_ctx *x = m->ctx[r];
+                e = m->staging[r].ensure(filmFloats * sizeof(float));
+                if (e == hipSuccess) e = x->device == root->device ? hipMemcpyAsync(m->staging[r].p, x->film.p, filmFloats * sizeof(float), hipMemcpyDeviceToDevice, root->stream)
+                                                                   : hipMemcpyPeerAsync(m->staging[r].p, root->device, x->film.p, x->device, filmFloats * sizeof(float), root->stream);
+                if (e == hipSuccess) { launchAddFilm(root->stream, rootDevFilm, (const float *)m->staging[r].p, filmFloats); e = hipGetLastError(); }
+            }
+        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(root->stream);
+    if (e != hipSuccess) return mfail(m, KKD_ERR_DEVICE, std::string("film merge: ") + hipGetErrorString(e));
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        for (uint32_t r = 0; r < n; ++r) {
+            const kkd_stats &s = st[r];
+            stats->samples += s.samples; stats->rays_closest += s.rays_closest; stats->rays_shadow += s.rays_shadow;
+            stats->algorithmic_bytes += s.algorithmic_bytes; stats->nodes_visited += s.nodes_visited; stats->tris_tested += s.tris_tested;
+            for (int k = 0; k < 3; ++k) { stats->class_rays[k] += s.class_rays[k]; stats->class_nodes[k] += s.class_nodes[k]; stats->class_tris[k] += s.class_tris[k]; }
+            for (int k = 0; k < 5; ++k) { stats->stage_seconds[k] += s.stage_seconds[k]; stats->stage_launches[k] += s.stage_launches[k]; }
+            stats->seconds_trace = std::max(stats->seconds_trace, s.seconds_trace);
+        }
+        stats->seconds = wall;           /* host wall clock of the whole job: the slowest device + the merge */
+    }
+    m->err.clear();
+    return KKD_OK;
+}
+
+int kkd_multi_render_device(kkd_multi *m, const kkd_render_params *params, void *dev_film, kkd_stats *stats) {
+    if (!m) return KKD_ERR_INVALID;
+    if (!dev_film) return mfail(m, KKD_ERR_INVALID, "kkd_multi_render_device: film buffer is NULL");
+    return multiRender(m, params, (float *)dev_film, stats);
+}
+
+int kkd_multi_render(kkd_multi *m, const kkd_render_params *params, float *out_film, kkd_stats *stats) {
+    if (!m) return KKD_ERR_INVALID;
+    if (!out_film) return mfail(m, KKD_ERR_INVALID, "kkd_multi_render: film buffer is NULL");
+    if (!m->haveScene) return mfail(m, KKD_ERR_INVALID, "no scene uploaded");
+    kkd_ctx *root = m->ctx[0];
+    const size_t bytes = (size_t)root->ds.sensor.cropW * root->ds.sensor.cropH * 5 * sizeof(float);
+    hipSetDevice(root->device);
+    hipError_t e = m->rootFilm.ensure(bytes);
+    if (e != hipSuccess) return mfail(m, e == hipErrorOutOfMemory ? KKD_ERR_NOMEM : KKD_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+    int rc = multiRender(m, params, (float *)m->rootFilm.p, stats);
+    if (rc != KKD_OK) return rc;
+    hipSetDevice(root->device);
+    e = hipMemcpy(out_film, m->rootFilm.p, bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return mfail(m, KKD_ERR_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e));
+    return KKD_OK;
 }
 
 } /* extern "C" */

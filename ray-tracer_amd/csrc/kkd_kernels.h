@@ -29,6 +29,10 @@ struct BatchParams {
     uint32_t bs, bsPow2, nbx, nby, tileIndex, tileCount, nTilesMine;
     int32_t W, H;
     int32_t edge;                    /* Film::hasHighQualityEdges: filter border by which the sampled area grows on every side, else 0 */
+    /* tile sharding (tileCount > 1): the tiles of this context, row-major tile ids in the order they are rendered
+     * (nTilesMine entries, device memory); nullptr = all tiles, tile id = running index.  The host deals the tiles out
+     * round-robin along the Morton curve of the tile grid, so every rank's tiles are spread over the whole image. */
+    const uint32_t *tileList;
     uint32_t debug;                  /* developer ablation bits from $KKD_DEBUG: 1 = no film atomics, 2 = no BSDF-hit evaluation, 4 = no block-level film reduction, 64 = per-lane primary walk */
 };
 
@@ -72,6 +76,17 @@ static constexpr uint32_t kAliveShards = 64;
 struct PathLaunch { uint32_t nIn, identity, compact, terminate; uint32_t *counters; };
 void launchPathBounce(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &in, const WaveBuffers &out, const PathLaunch &pl);
 void launchDevelop(hipStream_t st, const float *film, uint64_t nPixels, int pixelFormat, float *out);
+/* film merge of the tile-sharded multi-device render (BlockedRenderProcess::processResult -> Film::put(block),
+ * reference src/librender/renderproc.cpp:142-149, src/films/hdrfilm.cpp:391-393): a rank's tiles, each with its filter
+ * border, are packed into a dense buffer ((bs + 2 border)^2 * 5 floats per tile), moved to the root device in one copy
+ * and added into the root's film there.  A rank renders all its tiles into ONE film, so where the regions of two of its
+ * tiles overlap the film already holds their sum: such a pixel is packed only with the lowest-numbered tile of the rank
+ * whose region covers it. */
+struct TileGrid { uint32_t bs, nbx, nby; int32_t border, edge, W, H; const uint32_t *rankOf; /* rank of every tile (pack only) */ uint32_t myRank; };
+void launchPackTiles(hipStream_t st, const float *film, float *packed, const uint32_t *tileList, uint32_t nTiles, const TileGrid &g);
+void launchUnpackAddTiles(hipStream_t st, float *film, const float *packed, const uint32_t *tileList, uint32_t nTiles, const TileGrid &g);
+/* dst[i] += src[i]: merge of whole films (sample-split mode without RCCL) */
+void launchAddFilm(hipStream_t st, float *dst, const float *src, uint64_t n);
 void launchResolve(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb, float *film, DeviceCounters *ctr);
 
 } /* namespace kkd */

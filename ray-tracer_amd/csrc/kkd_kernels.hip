@@ -53,7 +53,7 @@ __device__ __forceinline__ SampleId mapWorkItem(const BatchParams &bp, uint32_t 
     if (bp.pixShift < 32u) { tAdd = p >> bp.pixShift; pin = p & (pixPerTile - 1u); }
     else { tAdd = p / pixPerTile; pin = p - tAdd * pixPerTile; }
     const uint32_t tileLocal = bp.tile0 + tAdd;
-    const uint32_t tile = bp.tileIndex + tileLocal * bp.tileCount;
+    const uint32_t tile = bp.tileList ? bp.tileList[min(tileLocal, bp.nTilesMine - 1u)] : tileLocal;   /* (lanes past the end are inactive) */
     const uint32_t ty = tile / bp.nbx, tx = tile - ty * bp.nbx;
     uint32_t px, py;
     if (bp.bsPow2) { px = compact1by1(pin); py = compact1by1(pin >> 1); }
@@ -745,6 +745,44 @@ __global__ void __launch_bounds__(256) kDevelop(const float *__restrict__ film, 
     }
 }
 
+/* ---- film merge of multi-device renders ---------------------------------------------------------------------------- */
+template <bool UNPACK>
+__global__ void __launch_bounds__(256) kTilesPackUnpack(float *__restrict__ film, float *__restrict__ packed, const uint32_t *__restrict__ tileList,
+                                                        uint32_t nTiles, TileGrid g) {
+    const uint32_t side = g.bs + 2u * (uint32_t)g.border, perTile = side * side;
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;          /* one thread per packed pixel (5 floats) */
+    if (i >= (uint64_t)nTiles * perTile) return;
+    const uint32_t k = (uint32_t)(i / perTile), r = (uint32_t)(i - (uint64_t)k * perTile), py = r / side, px = r - py * side;
+    const uint32_t tile = tileList[k], ty = tile / g.nbx, tx = tile - ty * g.nbx;
+    const int x = (int)(tx * g.bs + px) - g.border - g.edge, y = (int)(ty * g.bs + py) - g.border - g.edge;
+    bool inside = x >= 0 && x < g.W && y >= 0 && y < g.H;
+    if (!UNPACK && inside) {
+        /* the owner of the pixel and its eight neighbours are the only tiles whose regions can cover it (border < bs) */
+        const int ox = (x + g.edge) / (int)g.bs, oy = (y + g.edge) / (int)g.bs;
+        for (int dy = -1; dy <= 1 && inside; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int nx = ox + dx, ny = oy + dy;
+                if (nx < 0 || ny < 0 || nx >= (int)g.nbx || ny >= (int)g.nby) continue;
+                const uint32_t other = (uint32_t)ny * g.nbx + (uint32_t)nx;
+                if (other >= tile || g.rankOf[other] != g.myRank) continue;
+                const int x0 = nx * (int)g.bs - g.edge - g.border, y0 = ny * (int)g.bs - g.edge - g.border, side2 = (int)g.bs + 2 * g.border;
+                if (x >= x0 && x < x0 + side2 && y >= y0 && y < y0 + side2) { inside = false; break; }
+            }
+    }
+    float *p = packed + i * 5;
+    float *f = film + ((size_t)(inside ? y : 0) * g.W + (inside ? x : 0)) * 5;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        if (UNPACK) { if (inside && p[c] != 0.f) atomicAdd(f + c, p[c]); }      /* borders of neighbouring tiles overlap */
+        else p[c] = inside ? f[c] : 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256) kAddFilm(float *__restrict__ dst, const float *__restrict__ src, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
 /* ---- host launchers ---------------------------------------------------------------------------------- */
 static inline uint32_t blocksFor(uint64_t n, uint32_t block) { return (uint32_t)((n + block - 1) / block); }
 
@@ -839,6 +877,20 @@ void launchDevelop(hipStream_t st, const float *film, uint64_t n, int fmt, float
         case KKD_PIXEL_XYZ: hipLaunchKernelGGL(kDevelop<KKD_PIXEL_XYZ>, grid, block, 0, st, film, n, out); break;
         default: hipLaunchKernelGGL(kDevelop<KKD_PIXEL_XYZA>, grid, block, 0, st, film, n, out); break;
     }
+}
+
+void launchPackTiles(hipStream_t st, const float *film, float *packed, const uint32_t *tileList, uint32_t nTiles, const TileGrid &g) {
+    const uint64_t side = g.bs + 2u * (uint32_t)g.border, n = (uint64_t)nTiles * side * side;
+    if (n) hipLaunchKernelGGL(kTilesPackUnpack<false>, dim3(blocksFor(n, 256)), dim3(256), 0, st, const_cast<float *>(film), packed, tileList, nTiles, g);
+}
+
+void launchUnpackAddTiles(hipStream_t st, float *film, const float *packed, const uint32_t *tileList, uint32_t nTiles, const TileGrid &g) {
+    const uint64_t side = g.bs + 2u * (uint32_t)g.border, n = (uint64_t)nTiles * side * side;
+    if (n) hipLaunchKernelGGL(kTilesPackUnpack<true>, dim3(blocksFor(n, 256)), dim3(256), 0, st, film, const_cast<float *>(packed), tileList, nTiles, g);
+}
+
+void launchAddFilm(hipStream_t st, float *dst, const float *src, uint64_t n) {
+    if (n) hipLaunchKernelGGL(kAddFilm, dim3(blocksFor(n, 256)), dim3(256), 0, st, dst, src, n);
 }
 
 void launchResolve(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb, float *film, DeviceCounters *ctr) {

@@ -160,6 +160,78 @@ class Context:
         self.lib.kkd_request_cancel(self.h)
 
 
+class MultiContext:
+    """One kkd_multi: several GPUs of one node behind one handle (tile-sharded or sample-split, include/kkdirect.h)."""
+
+    def __init__(self, devices, split="tile", seed=1, max_samples_in_flight=0, projection_test=False):
+        self.lib = load_library()
+        self._devs = (abi.i32 * len(devices))(*devices)
+        cfg = abi.MultiConfig(len(devices), {"tile": abi.SPLIT_TILE, "sample": abi.SPLIT_SAMPLE}[split], self._devs,
+                              abi.FLAG_PROJECTION_TEST if projection_test else 0, 0, seed, max_samples_in_flight)
+        self.h = self.lib.kkd_multi_create(C.byref(cfg))
+        if not self.h:
+            raise KKDError(abi.KKD_ERR_DEVICE, self.lib.kkd_multi_last_error(None).decode())
+        self.width = self.height = 0
+        self._scene = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.kkd_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != abi.KKD_OK:
+            raise KKDError(rc, self.lib.kkd_multi_last_error(self.h).decode())
+
+    def upload(self, scene):
+        d = scene.desc()
+        self._check(self.lib.kkd_multi_scene_upload(self.h, C.byref(d)))
+        self._scene = scene
+        self.width, self.height = d.sensor.crop_width, d.sensor.crop_height
+        return self
+
+    def set_progress_callback(self, fn):
+        """fn(work_items_done, work_items_total) over all devices (kkd_multi_set_progress_callback); None removes it."""
+        self._progress = abi.PROGRESS_FN(lambda user, done, total: fn(done, total)) if fn else abi.PROGRESS_FN()
+        self._check(self.lib.kkd_multi_set_progress_callback(self.h, self._progress, None))
+
+    @property
+    def merge_path(self):
+        return self.lib.kkd_multi_merge_path(self.h).decode()
+
+    def render(self, spp, bsdf_samples=1, light_samples=1, hide_emitters=False, block_size=0, tile_index=0, tile_count=1,
+               sample_first=0, integrator=abi.INTEGRATOR_KK, strict_normals=False, max_depth=-1, rr_depth=5):
+        p = Context._params(spp, bsdf_samples, light_samples, hide_emitters, block_size, tile_index, tile_count, sample_first,
+                            integrator, strict_normals, max_depth, rr_depth)
+        film = np.zeros((self.height, self.width, 5), np.float32)
+        st = abi.Stats()
+        self._check(self.lib.kkd_multi_render(self.h, C.byref(p), film.ctypes.data_as(abi.pf32), C.byref(st)))
+        return film, st
+
+    def render_device(self, dev_ptr, spp, bsdf_samples=1, light_samples=1, hide_emitters=False, block_size=0, tile_index=0,
+                      tile_count=1, sample_first=0, integrator=abi.INTEGRATOR_KK, strict_normals=False, max_depth=-1, rr_depth=5):
+        p = Context._params(spp, bsdf_samples, light_samples, hide_emitters, block_size, tile_index, tile_count, sample_first,
+                            integrator, strict_normals, max_depth, rr_depth)
+        st = abi.Stats()
+        self._check(self.lib.kkd_multi_render_device(self.h, C.byref(p), C.c_void_p(dev_ptr), C.byref(st)))
+        return st
+
+    def request_cancel(self):
+        self.lib.kkd_multi_request_cancel(self.h)
+
+
 def develop(film):
     """HDRFilm::develop's normalisation on the host (reference src/libcore/fmtconv.cpp:978-989): RGB * (w != 0 ? 1/w : 0)."""
     film = np.asarray(film, np.float32)

@@ -71,6 +71,13 @@ class Config(C.Structure):
     _fields_ = [("device", i32), ("flags", u32), ("seed", u64), ("max_samples_in_flight", u64)]
 
 
+class MultiConfig(C.Structure):
+    _fields_ = [("n_devices", u32), ("split", u32), ("devices", C.POINTER(i32)), ("flags", u32), ("reserved", u32),
+                ("seed", u64), ("max_samples_in_flight", u64)]
+
+
+SPLIT_TILE, SPLIT_SAMPLE = 0, 1
+
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64)
 
 
@@ -128,6 +135,16 @@ ENTRY_POINTS = {
     "kkd_mesh_free": (None, [C.POINTER(Mesh)]),
     "kkd_request_cancel": (None, [C.c_void_p]),
     "kkd_set_progress_callback": (C.c_int, [C.c_void_p, PROGRESS_FN, C.c_void_p]),
+    "kkd_multi_create": (C.c_void_p, [C.POINTER(MultiConfig)]),
+    "kkd_multi_scene_upload": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
+    "kkd_multi_render": (C.c_int, [C.c_void_p, C.POINTER(RenderParams), pf32, C.POINTER(Stats)]),
+    "kkd_multi_render_device": (C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]),
+    "kkd_multi_request_cancel": (None, [C.c_void_p]),
+    "kkd_multi_set_progress_callback": (C.c_int, [C.c_void_p, PROGRESS_FN, C.c_void_p]),
+    "kkd_multi_merge_path": (C.c_char_p, [C.c_void_p]),
+    "kkd_multi_device_count": (u32, [C.c_void_p]),
+    "kkd_multi_last_error": (C.c_char_p, [C.c_void_p]),
+    "kkd_multi_destroy": (None, [C.c_void_p]),
     "kkd_last_error": (C.c_char_p, [C.c_void_p]),
     "kkd_destroy": (None, [C.c_void_p]),
 }

@@ -124,7 +124,7 @@ def test_adapter_source_uses_only_declared_abi():
     for name in sorted(set(re.findall(r"\b(?:kkd_[a-z_0-9]+|KKD_[A-Z_0-9]+)\b", src))):
         assert re.search(r"\b%s\b" % name, hdr), name
     fields = {"sh": "kkd_shape", "ke": "kkd_emitter", "env": "kkd_envmap", "ks": "kkd_sensor", "sd": "kkd_scene_desc",
-              "cfg": "kkd_config", "rp": "kkd_render_params", "st": "kkd_stats"}
+              "cfg": "kkd_multi_config", "rp": "kkd_render_params", "st": "kkd_stats"}
     for var, struct in fields.items():
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), hdr, re.S).group(1)
         for f in sorted(set(re.findall(r"\b%s\.([a-z_0-9]+)" % var, src))):

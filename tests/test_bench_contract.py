@@ -32,3 +32,34 @@ def test_bench_line_has_the_contract_fields():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] <= 1.0
     assert r["traffic"] is None          # no PMC summary matches this reduced configuration: nothing is borrowed from another run
     assert r["avg_launch_ms"] > 0 and r["launches"] > 0 and sum(r["stage_ms_per_step"].values()) > 0
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_the_gpu_and_merge_their_films():
+    """The N-rank path of bench.py on the one GPU of the test box: two processes started by torch.distributed.run, each
+    with its own kkd_ctx rendering its tiles into a device film, films merged through torch.distributed (gloo here: two
+    ranks on one device cannot form an RCCL communicator; the measured configuration is always nccl = RCCL).  The merged
+    film must hold every sample of both ranks: its weight channel sums to the number of samples."""
+    env = dict(os.environ, KKD_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for split in ("tile", "sample"):
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                              "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c2", "--steps", "2", "--warmup", "1",
+                              "--scale", "0.25", "--spp", "16", "--split", split, "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["split"] == split and j["config"]["spp_total"] == 32
+        assert j["value"] > 0 and abs(j["config"]["film_weight_per_sample"] - 1.0) < 0.02, j["config"]
+
+
+@pytest.mark.gpu
+def test_single_process_multi_device_bench_path():
+    """python bench.py --gpus N without a launcher drives the library's own multi-device entry points; with one visible GPU
+    only N = 1 can run here -- the N > 1 request must be refused, not silently narrowed"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c1", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert out.returncode != 0 and "devices visible" in out.stderr
+    else:
+        j = json.loads(out.stdout.splitlines()[-1])
+        assert j["n_gpus"] == 2 and "in-library" in j["config"]["multi_gpu"]
