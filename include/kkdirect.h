@@ -171,6 +171,11 @@ typedef struct kkd_scene_desc {
                                         idle); with this flag batches run one after the other on the context's stream, so that
                                         kkd_stats.stage_seconds are the kernels' exclusive durations (measurement runs) */
 
+#define KKD_FLAG_GPU_BUILD 8u        /* build the acceleration structure on the device (Morton-ordered linear BVH, milliseconds for
+                                        10 M triangles) instead of on the host (binned SAH, seconds): for callers whose scenes change
+                                        from frame to frame; the host tree is tighter and stays the default.  Replaces the same step,
+                                        ShapeKDTree::build (src/librender/skdtree.cpp:68-110); hits do not depend on the choice */
+
 typedef struct kkd_config {
     int32_t  device;           /* HIP device ordinal                                           */
     uint32_t flags;            /* KKD_FLAG_*                                                   */

@@ -19,6 +19,7 @@
 #include <vector>
 #include "kkd_host.h"
 #include "kkd_kernels.h"
+#include "kkd_gpu_build.h"
 
 using namespace kkd;
 
@@ -191,7 +192,9 @@ void kkd_destroy(kkd_ctx *ctx) {
 /* host half of kkd_scene_upload: validate + flatten + build (once per scene, whatever the number of devices) */
 static int buildHostScene(kkd_ctx *ctx, const kkd_scene_desc *sd, HostScene &hs) {
     int code = KKD_ERR_INVALID;
-    if (!flattenScene(sd, hs, ctx->err, &code)) return code;
+    const bool gpuBuild = (ctx->cfg.flags & KKD_FLAG_GPU_BUILD) != 0;
+    if (!flattenScene(sd, hs, ctx->err, &code, !gpuBuild)) return code;
+    if (gpuBuild) return KKD_OK;          /* the tree is built by uploadHostScene, on the device */
     /* the kernels index their stack without a bound check: the builder's worst-case occupancy must fit */
     if (hs.bvh.info.maxStack > kMaxTraversalStack) return fail(ctx, KKD_ERR_UNSUPPORTED, "acceleration structure deeper than the traversal stack");
     for (LeafTri &t : hs.bvh.tris) { const int32_t e = hs.shapes[t.shape].emitter; t.emitter = e >= 0 ? (uint32_t)e + 1u : 0u; }
@@ -203,13 +206,16 @@ static int uploadHostScene(kkd_ctx *ctx, const HostScene &hs, const kkd_scene_de
     KKD_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
 #define UP(buf, ptr, n) if ((rc = upload(ctx, ctx->buf, ptr, n)) != KKD_OK) return rc;
-    UP(nodes, hs.bvh.nodes.data(), hs.bvh.nodes.size())
-    UP(wideNodes, hs.bvh.wide.data(), hs.bvh.wide.size())
-    UP(tris, hs.bvh.tris.data(), hs.bvh.tris.size())
+    const bool gpuBuild = (ctx->cfg.flags & KKD_FLAG_GPU_BUILD) != 0;
     std::vector<ProjTri> pt;   /* read by an asynchronous copy: lives until the stream has been synchronised below */
-    if (ctx->cfg.flags & KKD_FLAG_PROJECTION_TEST) {
-        makeProjTris(hs.bvh.tris, pt);
-        UP(projTris, pt.data(), pt.size())
+    if (!gpuBuild) {
+        UP(nodes, hs.bvh.nodes.data(), hs.bvh.nodes.size())
+        UP(wideNodes, hs.bvh.wide.data(), hs.bvh.wide.size())
+        UP(tris, hs.bvh.tris.data(), hs.bvh.tris.size())
+        if (ctx->cfg.flags & KKD_FLAG_PROJECTION_TEST) {
+            makeProjTris(hs.bvh.tris, pt);
+            UP(projTris, pt.data(), pt.size())
+        }
     }
     UP(positions, sd->positions, 3 * (size_t)sd->n_verts)
     UP(normals, sd->normals, sd->normals ? 3 * (size_t)sd->n_verts : 0)
@@ -231,6 +237,29 @@ static int uploadHostScene(kkd_ctx *ctx, const HostScene &hs, const kkd_scene_de
     UP(envGuideCols, hs.envGuideCols.data(), hs.envGuideCols.size())
 #undef UP
     KKD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BVH4::Info accel = hs.bvh.info;
+    if (gpuBuild) {
+        /* KKD_FLAG_GPU_BUILD: the tree is built from the vertex and index arrays that are on the device already */
+        const uint32_t nTris = (uint32_t)sd->n_tris;
+        hipError_t e = ctx->nodes.ensure((size_t)nTris * sizeof(Node4));
+        if (e == hipSuccess) e = ctx->wideNodes.ensure((size_t)nTris * sizeof(WideNode));
+        if (e == hipSuccess) e = ctx->tris.ensure((size_t)nTris * sizeof(LeafTri));
+        if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? KKD_ERR_NOMEM : KKD_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+        GpuBuildResult res{}; std::string berr;
+        e = gpuBuildBvh(ctx->stream, (const float *)ctx->positions.p, (const uint32_t *)ctx->indices.p, nTris, (const DShape *)ctx->shapes.p, (uint32_t)hs.shapes.size(),
+                        (Node4 *)ctx->nodes.p, (WideNode *)ctx->wideNodes.p, (LeafTri *)ctx->tris.p, nTris, &res, berr);
+        if (e != hipSuccess) return fail(ctx, e == hipErrorInvalidValue ? KKD_ERR_INVALID : (e == hipErrorOutOfMemory ? KKD_ERR_NOMEM : KKD_ERR_DEVICE), "device build: " + berr);
+        if (res.maxStack > kMaxTraversalStack) return fail(ctx, KKD_ERR_UNSUPPORTED, "acceleration structure deeper than the traversal stack");
+        accel = BVH4::Info(); accel.nNodes = res.nNodes; accel.nLeafTris = nTris; accel.maxDepth = res.maxDepth; accel.maxStack = res.maxStack;
+        if (ctx->cfg.flags & KKD_FLAG_PROJECTION_TEST) {
+            /* the TriAccel table follows the leaf order: read the leaf records back and build it as the host path does */
+            std::vector<LeafTri> lt(nTris);
+            KKD_HIP(ctx, hipMemcpy(lt.data(), ctx->tris.p, (size_t)nTris * sizeof(LeafTri), hipMemcpyDeviceToHost));
+            makeProjTris(lt, pt);
+            if ((rc = upload(ctx, ctx->projTris, pt.data(), pt.size())) != KKD_OK) return rc;
+            KKD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
     DScene &d = ctx->ds;
     std::memset(&d, 0, sizeof(d));
     d.nodes = (const Node4 *)ctx->nodes.p; d.tris = (const LeafTri *)ctx->tris.p; d.wideNodes = (const WideNode *)ctx->wideNodes.p;
@@ -247,7 +276,7 @@ static int uploadHostScene(kkd_ctx *ctx, const HostScene &hs, const kkd_scene_de
     d.env.cdfCols = (const float *)ctx->envCdfCols.p; d.env.rowWeights = (const float *)ctx->envRowWeights.p;
     d.env.guideRows = (const uint32_t *)ctx->envGuideRows.p; d.env.guideCols = (const uint32_t *)ctx->envGuideCols.p;
     d.sensor = hs.sensor; d.filter = hs.filter;
-    ctx->accelInfo = hs.bvh.info;
+    ctx->accelInfo = accel;
     ctx->tileKey[3] = 0;            /* a new film / tile grid: the cached tile list is stale */
     ctx->haveScene = true;
     ctx->err.clear();

@@ -11,10 +11,15 @@
  * largest surface area; nodes are emitted in depth-first order, triangles in leaf order.
  */
 #include "kkd_bvh.h"
+#include "kkd_bvh_encode.h"
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <future>
 #include <thread>
 
@@ -36,10 +41,8 @@ struct Box {
 
 struct Prim { Box box; float c[3]; uint32_t id; };
 
-/* builder-internal uncompressed 4-wide node */
-struct Node4F { float minx[4], miny[4], minz[4], maxx[4], maxy[4], maxz[4]; uint32_t child[4]; int nk; };
 
-struct Node2 { Box box; uint32_t left, right; uint32_t start, count; /* count > 0: leaf */ };
+struct Node2 { Box box; uint32_t left, right; uint32_t start, count; /* count > 0: leaf */ uint32_t span; /* primitives below */ };
 
 struct Builder {
     std::vector<Prim> prims;
@@ -55,29 +58,37 @@ struct Builder {
         const uint32_t n = hi - lo, me = alloc();
         Box box, cbox; box.reset(); cbox.reset();
         for (uint32_t i = lo; i < hi; ++i) { box.grow(prims[i].box); cbox.grow(prims[i].c); }
-        Node2 nd; nd.box = box; nd.left = nd.right = 0; nd.start = lo; nd.count = 0;
+        Node2 nd; nd.box = box; nd.left = nd.right = 0; nd.start = lo; nd.count = 0; nd.span = n;
         if (n <= 1) { nd.count = n; nodes[me] = nd; return me; }
-        /* binned SAH */
+        /* binned SAH: one pass over the primitives fills the bins of all three axes */
         int bestAxis = -1, bestBin = -1; float bestCost = INFINITY;
-        for (int ax = 0; ax < 3; ++ax) {
-            const float ext = cbox.mx[ax] - cbox.mn[ax];
-            if (!(ext > 0.f)) continue;
-            Box bb[kBins]; uint32_t cnt[kBins];
-            for (int b = 0; b < kBins; ++b) { bb[b].reset(); cnt[b] = 0; }
-            const float scale = kBins / ext;
-            for (uint32_t i = lo; i < hi; ++i) {
-                int b = std::min(kBins - 1, std::max(0, (int)((prims[i].c[ax] - cbox.mn[ax]) * scale)));
-                bb[b].grow(prims[i].box); cnt[b]++;
+        {
+            Box bb[3][kBins]; uint32_t cnt[3][kBins]; float scale[3]; bool use[3];
+            for (int ax = 0; ax < 3; ++ax) {
+                const float ext = cbox.mx[ax] - cbox.mn[ax];
+                use[ax] = ext > 0.f; scale[ax] = use[ax] ? kBins / ext : 0.f;
+                for (int k = 0; k < kBins; ++k) { bb[ax][k].reset(); cnt[ax][k] = 0; }
             }
-            float rightArea[kBins]; uint32_t rightCnt[kBins];
-            Box acc; acc.reset(); uint32_t c = 0;
-            for (int b = kBins - 1; b > 0; --b) { acc.grow(bb[b]); c += cnt[b]; rightArea[b] = acc.area(); rightCnt[b] = c; }
-            acc.reset(); c = 0;
-            for (int b = 0; b < kBins - 1; ++b) {
-                acc.grow(bb[b]); c += cnt[b];
-                if (c == 0 || rightCnt[b + 1] == 0) continue;
-                float cost = acc.area() * c + rightArea[b + 1] * rightCnt[b + 1];
-                if (cost < bestCost) { bestCost = cost; bestAxis = ax; bestBin = b; }
+            for (uint32_t i = lo; i < hi; ++i) {
+                const Prim &p = prims[i];
+                for (int ax = 0; ax < 3; ++ax) {
+                    if (!use[ax]) continue;
+                    const int k = std::min(kBins - 1, std::max(0, (int)((p.c[ax] - cbox.mn[ax]) * scale[ax])));
+                    bb[ax][k].grow(p.box); cnt[ax][k]++;
+                }
+            }
+            for (int ax = 0; ax < 3; ++ax) {
+                if (!use[ax]) continue;
+                float rightArea[kBins]; uint32_t rightCnt[kBins];
+                Box acc; acc.reset(); uint32_t c = 0;
+                for (int k = kBins - 1; k > 0; --k) { acc.grow(bb[ax][k]); c += cnt[ax][k]; rightArea[k] = acc.area(); rightCnt[k] = c; }
+                acc.reset(); c = 0;
+                for (int k = 0; k < kBins - 1; ++k) {
+                    acc.grow(bb[ax][k]); c += cnt[ax][k];
+                    if (c == 0 || rightCnt[k + 1] == 0) continue;
+                    float cost = acc.area() * c + rightArea[k + 1] * rightCnt[k + 1];
+                    if (cost < bestCost) { bestCost = cost; bestAxis = ax; bestBin = k; }
+                }
             }
         }
         const float leafCost = kTriCost * n;
@@ -118,9 +129,14 @@ struct Builder {
     }
 };
 
+/* Subtrees of at most deferBelow primitives are not collapsed by the caller's walk: it records them (in DFS order) and they are
+ * collapsed side by side into vectors of their own, which are then appended -- nodes after the top of the tree, triangles in
+ * the same leaf order as one serial walk gives. */
+struct Deferred { uint32_t root; uint32_t parent; int slot; int depth, stackAbove; };
 struct Collapser {
     const Builder &b; const float *pos; const uint32_t *idx; const uint32_t *shapeOfPrim;
     std::vector<Node4F> &out; std::vector<LeafTri> &tris; BVH4::Info &info;
+    uint32_t deferBelow = 0; std::vector<Deferred> *deferred = nullptr;
 
     uint32_t emitLeaf(const Node2 &n) {
         const uint32_t start = (uint32_t)tris.size();
@@ -167,7 +183,8 @@ struct Collapser {
             const Node2 &c = b.nodes[kids[k]];
             nd.minx[k] = c.box.mn[0]; nd.miny[k] = c.box.mn[1]; nd.minz[k] = c.box.mn[2];
             nd.maxx[k] = c.box.mx[0]; nd.maxy[k] = c.box.mx[1]; nd.maxz[k] = c.box.mx[2];
-            nd.child[k] = emit(kids[k], depth + 1, stackHere);
+            if (deferred && c.count == 0 && c.span <= deferBelow) { deferred->push_back(Deferred{ kids[k], me, k, depth + 1, stackHere }); nd.child[k] = 0; }
+            else nd.child[k] = emit(kids[k], depth + 1, stackHere);
         }
         out[me] = nd;
         return me;
@@ -176,87 +193,47 @@ struct Collapser {
 
 } /* namespace */
 
-/* 8-bit grid encoding of a node's child boxes (layout: kkd_types.h).  Per axis: origin = min over the children,
- * scale = smallest power of two with extent <= 255 * scale; min planes round down, max planes up, and every plane is
- * checked through the kernel's own decode, fmaf(q, scale, origin), so the decoded box always encloses the true one. */
-static inline float decodePlane(uint8_t q, float scale, float origin) { return std::fmaf((float)q, scale, origin); }
-
-/* float boxes relative to the node's min corner, rounded outwards (so that origin + rel encloses the true plane) */
-static void widenNode(const Node4F &n, WideNode &out) {
-    std::memset(&out, 0, sizeof(out));
-    const float *mins[3] = { n.minx, n.miny, n.minz }, *maxs[3] = { n.maxx, n.maxy, n.maxz };
-    float *rmins[3] = { out.rminx, out.rminy, out.rminz }, *rmaxs[3] = { out.rmaxx, out.rmaxy, out.rmaxz };
-    float origin[3];
-    for (int a = 0; a < 3; ++a) {
-        float lo = INFINITY;
-        for (int k = 0; k < n.nk; ++k) lo = std::min(lo, mins[a][k]);
-        origin[a] = lo;
-        for (int k = 0; k < 4; ++k) {
-            if (k >= n.nk) { rmins[a][k] = INFINITY; rmaxs[a][k] = INFINITY; continue; }
-            float r0 = mins[a][k] - lo, r1 = maxs[a][k] - lo;
-            while (lo + r0 > mins[a][k]) r0 = std::nextafter(r0, -INFINITY);
-            while (lo + r1 < maxs[a][k]) r1 = std::nextafter(r1, INFINITY);
-            rmins[a][k] = r0; rmaxs[a][k] = r1;
-        }
-    }
-    out.ox = origin[0]; out.oy = origin[1]; out.oz = origin[2];
-    for (int k = 0; k < 4; ++k) out.child[k] = k < n.nk ? n.child[k] : 0u;
-}
-
-static void quantizeNode(const Node4F &n, Node4 &out) {
-    std::memset(&out, 0, sizeof(out));
-    const float *mins[3] = { n.minx, n.miny, n.minz }, *maxs[3] = { n.maxx, n.maxy, n.maxz };
-    uint8_t *qmins[3] = { out.qminx, out.qminy, out.qminz }, *qmaxs[3] = { out.qmaxx, out.qmaxy, out.qmaxz };
-    float origin[3]; uint8_t expo[3];
-    for (int a = 0; a < 3; ++a) {
-        float lo = INFINITY, hi = -INFINITY;
-        for (int k = 0; k < n.nk; ++k) { lo = std::min(lo, mins[a][k]); hi = std::max(hi, maxs[a][k]); }
-        origin[a] = lo;
-        const float extent = hi - lo;
-        int e = 0;                                   /* scale = 2^e */
-        if (extent > 0.f) { std::frexp(extent / 255.0f, &e); }   /* extent/255 = m * 2^e, m in [0.5,1) => 2^e >= extent/255 */
-        else e = -126;
-        e = std::max(-126, std::min(127, e));
-        float scale = std::ldexp(1.0f, e);
-        /* make sure the top of the range is reachable after float rounding of the decode */
-        while (e < 127 && decodePlane(255, scale, lo) < hi) { ++e; scale = std::ldexp(1.0f, e); }
-        expo[a] = (uint8_t)(e + 127);
-        for (int k = 0; k < 4; ++k) {
-            if (k >= n.nk) { qmins[a][k] = 255; qmaxs[a][k] = 0; continue; }
-            int q0 = (int)std::floor((mins[a][k] - lo) / scale), q1 = (int)std::ceil((maxs[a][k] - lo) / scale);
-            q0 = std::max(0, std::min(255, q0)); q1 = std::max(0, std::min(255, q1));
-            while (q0 > 0 && decodePlane((uint8_t)q0, scale, lo) > mins[a][k]) --q0;
-            while (q1 < 255 && decodePlane((uint8_t)q1, scale, lo) < maxs[a][k]) ++q1;
-            qmins[a][k] = (uint8_t)q0; qmaxs[a][k] = (uint8_t)q1;
-        }
-    }
-    out.ox = origin[0]; out.oy = origin[1]; out.oz = origin[2];
-    out.ex = expo[0]; out.ey = expo[1]; out.ez = expo[2]; out.epad = 0;
-    for (int k = 0; k < 4; ++k) out.child[k] = k < n.nk ? n.child[k] : 0u;
-}
-
 bool BVH4::build(const float *positions, const uint32_t *indices, uint64_t nTris, const uint32_t *shapeOfPrim, std::string &err) {
     nodes.clear(); this->wide.clear(); tris.clear(); info = Info();
     if (nTris == 0) { err = "scene has no triangles"; return false; }
     if (nTris > (uint64_t)kLeafStartMask) { err = "too many triangles for the 28-bit leaf slot field"; return false; }
-    Builder b;
-    b.prims.reserve(nTris);
-    for (uint64_t p = 0; p < nTris; ++p) {
-        Prim pr; pr.box.reset(); pr.id = (uint32_t)p;
-        bool finite = true;
-        for (int k = 0; k < 3; ++k) {
-            const float *v = positions + 3 * (size_t)indices[3 * p + k];
-            for (int a = 0; a < 3; ++a) if (!std::isfinite(v[a])) finite = false;
-            pr.box.grow(v);
-        }
-        if (!finite) { err = "non-finite vertex position"; return false; }
-        for (int a = 0; a < 3; ++a) pr.c[a] = 0.5f * (pr.box.mn[a] + pr.box.mx[a]);
-        b.prims.push_back(pr);
-    }
-    b.nodes.resize(2 * nTris);
+    const bool timing = getenv("KKD_BVH_TIMING") != nullptr;
+    auto tPrev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (!timing) return; auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "bvh: %-10s %.3f s\n", what, std::chrono::duration<double>(t - tPrev).count()); tPrev = t; };
     unsigned hw = std::thread::hardware_concurrency();
-    b.freeThreads = (int)std::min(16u, hw ? hw : 1u) - 1;
+    const unsigned nThreads = std::min(16u, hw ? hw : 1u);
+    /* run f(begin, end) over [0, n) on the builder's threads */
+    auto parallelFor = [&](size_t n, const std::function<void(size_t, size_t)> &f) {
+        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(nThreads, n / 65536));
+        if (nt <= 1) { f(0, n); return; }
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t) th.emplace_back(f, n * t / nt, n * (t + 1) / nt);
+        for (std::thread &x : th) x.join();
+    };
+    Builder b;
+    b.prims.resize(nTris);
+    std::atomic<bool> allFinite{true};
+    parallelFor(nTris, [&](size_t lo, size_t hi) {
+        bool finite = true;
+        for (size_t p = lo; p < hi; ++p) {
+            Prim pr; pr.box.reset(); pr.id = (uint32_t)p;
+            for (int k = 0; k < 3; ++k) {
+                const float *v = positions + 3 * (size_t)indices[3 * p + k];
+                for (int a = 0; a < 3; ++a) if (!std::isfinite(v[a])) finite = false;
+                pr.box.grow(v);
+            }
+            for (int a = 0; a < 3; ++a) pr.c[a] = 0.5f * (pr.box.mn[a] + pr.box.mx[a]);
+            b.prims[p] = pr;
+        }
+        if (!finite) allFinite = false;
+    });
+    if (!allFinite) { err = "non-finite vertex position"; return false; }
+    b.nodes.resize(2 * nTris);
+    b.freeThreads = (int)nThreads - 1;
+    lap("prims");
     const uint32_t root = b.build(0, (uint32_t)nTris, 0);
+    lap("sah build");
     tris.reserve(nTris);
     std::vector<Node4F> wide;
     wide.reserve(nTris / 2 + 16);
@@ -277,10 +254,45 @@ bool BVH4::build(const float *positions, const uint32_t *indices, uint64_t nTris
         wide[0] = nd;
         info.maxDepth = 1; info.maxStack = 0;
     } else {
+        std::vector<Deferred> deferred;
+        if (nThreads > 1 && nTris > 262144) { c.deferBelow = (uint32_t)std::max<uint64_t>(65536, nTris / (8 * nThreads)); c.deferred = &deferred; }
         c.emit(root, 0, 0);
+        if (!deferred.empty()) {
+            /* the deferred subtrees, collapsed side by side into their own vectors (local node indices and leaf slots) */
+            struct Part { std::vector<Node4F> nodes; std::vector<LeafTri> tris; BVH4::Info info; uint32_t ref = 0; };
+            std::vector<Part> parts(deferred.size());
+            std::atomic<size_t> next{0};
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < std::min<size_t>(nThreads, deferred.size()); ++t) th.emplace_back([&] {
+                for (size_t k; (k = next.fetch_add(1)) < deferred.size();) {
+                    Part &p = parts[k];
+                    p.tris.reserve(b.nodes[deferred[k].root].span);
+                    Collapser sub{ b, positions, indices, shapeOfPrim, p.nodes, p.tris, p.info };
+                    p.ref = sub.emit(deferred[k].root, deferred[k].depth, deferred[k].stackAbove);
+                }
+            });
+            for (std::thread &x : th) x.join();
+            /* append in DFS order of their roots; local references move by the part's base */
+            for (size_t k = 0; k < parts.size(); ++k) {
+                Part &p = parts[k];
+                const uint32_t nodeBase = (uint32_t)wide.size(), triBase = (uint32_t)tris.size();
+                auto moved = [&](uint32_t ref) { return ref == 0u ? 0u : ((ref & kLeafBit) ? ref + triBase : ref + nodeBase); };
+                for (Node4F &nd : p.nodes) for (int q = 0; q < 4; ++q) nd.child[q] = moved(nd.child[q]);
+                /* the part's root is its local node 0: a valid reference here, not the "empty slot" marker */
+                wide[deferred[k].parent].child[deferred[k].slot] = (p.ref & kLeafBit) ? p.ref + triBase : p.ref + nodeBase;
+                wide.insert(wide.end(), p.nodes.begin(), p.nodes.end());
+                tris.insert(tris.end(), p.tris.begin(), p.tris.end());
+                info.maxDepth = std::max(info.maxDepth, p.info.maxDepth); info.maxStack = std::max(info.maxStack, p.info.maxStack);
+                std::vector<Node4F>().swap(p.nodes); std::vector<LeafTri>().swap(p.tris);
+            }
+        }
     }
+    lap("collapse");
     nodes.resize(wide.size()); this->wide.resize(wide.size());
-    for (size_t i = 0; i < wide.size(); ++i) { quantizeNode(wide[i], nodes[i]); widenNode(wide[i], this->wide[i]); }
+    parallelFor(wide.size(), [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) { quantizeNode(wide[i], nodes[i]); widenNode(wide[i], this->wide[i]); }
+    });
+    lap("quantise");
     info.nNodes = nodes.size(); info.nLeafTris = tris.size();
     return true;
 }

@@ -254,7 +254,7 @@ static bool mat4inv(const double m[16], double out[16]) {
 
 #define KKD_FAIL(code, msg) do { err = (msg); if (errCode) *errCode = (code); return false; } while (0)
 
-bool flattenScene(const kkd_scene_desc *sd, HostScene &hs, std::string &err, int *errCode) {
+bool flattenScene(const kkd_scene_desc *sd, HostScene &hs, std::string &err, int *errCode, bool buildBvh) {
     if (!sd) KKD_FAIL(KKD_ERR_INVALID, "scene description is NULL");
     if (sd->abi_version != KKD_ABI_VERSION) KKD_FAIL(KKD_ERR_INVALID, "scene description has a different ABI version");
     if (!sd->positions || !sd->indices || !sd->n_verts || !sd->n_tris) KKD_FAIL(KKD_ERR_INVALID, "scene has no geometry");
@@ -507,7 +507,8 @@ bool flattenScene(const kkd_scene_desc *sd, HostScene &hs, std::string &err, int
     }
 
     /* acceleration structure */
-    if (!hs.bvh.build(sd->positions, sd->indices, sd->n_tris, hs.shapeOfPrim.data(), err)) { if (errCode) *errCode = KKD_ERR_INVALID; return false; }
+    if (sd->n_tris > (uint64_t)kLeafStartMask) KKD_FAIL(KKD_ERR_INVALID, "too many triangles for the 28-bit leaf slot field");
+    if (buildBvh && !hs.bvh.build(sd->positions, sd->indices, sd->n_tris, hs.shapeOfPrim.data(), err)) { if (errCode) *errCode = KKD_ERR_INVALID; return false; }
     return true;
 }
 

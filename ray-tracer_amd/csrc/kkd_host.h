@@ -37,7 +37,8 @@ struct HostScene {
 };
 
 /* Validates the description and fills everything except device pointers.  false + err on failure. */
-bool flattenScene(const kkd_scene_desc *sd, HostScene &hs, std::string &err, int *errCode);
+/* buildBvh = false: everything but the acceleration structure (KKD_FLAG_GPU_BUILD builds it on the device) */
+bool flattenScene(const kkd_scene_desc *sd, HostScene &hs, std::string &err, int *errCode, bool buildBvh = true);
 
 /* rough-dielectric transmittance T(cosTheta) for one (distribution, alpha, eta): 100 knots at
  * cosTheta^(1/4) = i/99 plus the diffuse transmittance (what bsdfs/rtrans.h yields after setEta/setAlpha). */

@@ -17,6 +17,7 @@ SHAPE_HAS_NORMALS, SHAPE_HAS_TEXCOORDS = 1, 2
 FLAG_COUNT_TRAVERSAL = 1
 FLAG_PROJECTION_TEST = 2
 FLAG_ONE_LANE = 4
+FLAG_GPU_BUILD = 8
 NOALLOC_MAX_RAYS = 1 << 30      # KKD_NOALLOC_MAX_RAYS
 PIXEL_LUMINANCE, PIXEL_LUMINANCE_ALPHA, PIXEL_RGB, PIXEL_RGBA, PIXEL_XYZ, PIXEL_XYZA = range(6)
 PIXEL_CHANNELS = {PIXEL_LUMINANCE: 1, PIXEL_LUMINANCE_ALPHA: 2, PIXEL_RGB: 3, PIXEL_RGBA: 4, PIXEL_XYZ: 3, PIXEL_XYZA: 4}
