@@ -29,7 +29,7 @@ def stage_of(name):
 def pmc(dirname):
     """-> {stage: {counter: [value per dispatch]}}; one value per (dispatch, counter), dimensions summed"""
     per = defaultdict(lambda: defaultdict(float)); stage_of_dispatch = {}
-    f = glob.glob(os.path.join(src, dirname, "*", "*counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(src, dirname, "*", "*counter_collection.csv")), key=os.path.getmtime)   # the latest run (older ones may linger)
     for row in csv.DictReader(open(f)):
         st = stage_of(row["Kernel_Name"])
         if st is None: continue
@@ -56,10 +56,11 @@ for st in STAGES:
     if s.get("SQ_WAVES"):
         rec.update({"valu_insts_per_wave": round(s["SQ_INSTS_VALU"] / s["SQ_WAVES"], 1), "salu_insts_per_wave": round(s["SQ_INSTS_SALU"] / s["SQ_WAVES"], 1),
                     "vmem_rd_insts_per_wave": round(s["SQ_INSTS_VMEM_RD"] / s["SQ_WAVES"], 1),
-                    # share of the cycles a wave is resident in which it waits on anything / share in which some VALU instruction of the
-                    # SIMD is executing (4 cycles per wave64 instruction): SQ_ACTIVE_INST_VALU * 4 / SQ_BUSY_CYCLES counts per SIMD-quad
+                    # share of the cycles a wave is resident in which it waits on anything
                     "wave_wait_share": round(s["SQ_WAIT_INST_ANY"] / max(1.0, s["SQ_WAVE_CYCLES"]), 4),
-                    "valu_issue_util": round(s["SQ_ACTIVE_INST_VALU"] / max(1.0, 4.0 * s["SQ_BUSY_CYCLES"]), 4)})
+                    # wave-level VALU instructions per kernel launch of the stage: bench.py divides by its own launch duration and by the
+                    # chip's issue peak (1024 SIMDs x one wave64 VALU instruction per 4 cycles)
+                    "valu_insts_per_launch": round(s["SQ_INSTS_VALU"] / max(1, len(sq[st]["SQ_INSTS_VALU"])))})
     if t.get("GRBM_GUI_ACTIVE"):
         rec["ta_busy_share"] = round(t.get("TA_BUSY_avr", 0.0) / max(1.0, t["GRBM_GUI_ACTIVE"]), 4)
     stages[st] = rec
