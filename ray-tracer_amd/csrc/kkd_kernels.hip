@@ -285,8 +285,13 @@ __device__ __forceinline__ void storeRay(DRay *dst, const DRay &r) {
 #ifndef KKD_SHADE_WAVES
 #define KKD_SHADE_WAVES 4      /* blocks of 256 per CU = waves per SIMD */
 #endif
-__global__ void __launch_bounds__(256, KKD_SHADE_WAVES) kShade(DScene sc, BatchParams bp, WaveBuffers wb) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+#ifndef KKD_SHADE_BLOCK
+#define KKD_SHADE_BLOCK 256    /* (one-wave workgroups were measured: with two batch lanes kShade then finishes in 52 instead of 130 ms per
+                                  64-spp C4 frame, but kResolve is starved instead, 120 instead of 42 ms: the frame time does not move, 198.0 vs
+                                  197.6 ms -- the pipeline as a whole is bound by VALU issue, lanes only redistribute it) */
+#endif
+__global__ void __launch_bounds__(KKD_SHADE_BLOCK, KKD_SHADE_WAVES * 256 / KKD_SHADE_BLOCK) kShade(DScene sc, BatchParams bp, WaveBuffers wb) {
+    const uint32_t i = blockIdx.x * KKD_SHADE_BLOCK + threadIdx.x;
     if (i >= bp.count) return;
     const SampleId s = mapWorkItem(bp, i);
     const uint32_t nB = bp.nB, nL = bp.nL;
@@ -858,7 +863,7 @@ void launchTracePhased(hipStream_t st, const DScene &sc, const DRay *rays, uint6
 }
 
 void launchShade(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb) {
-    hipLaunchKernelGGL(kShade, dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, wb);
+    hipLaunchKernelGGL(kShade, dim3(blocksFor(bp.count, KKD_SHADE_BLOCK)), dim3(KKD_SHADE_BLOCK), 0, st, sc, bp, wb);
 }
 
 void launchPathBounce(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &in, const WaveBuffers &out, const PathLaunch &pl) {
