@@ -404,6 +404,12 @@ int kkd_mesh_save_serialized(const char *path, const kkd_mesh *meshes, uint32_t 
  * triangles and quads (a quad becomes (0,1,2) + (3,0,2)); properties of other types are skipped as libply does. */
 int kkd_mesh_load_ply(const char *path, const float *to_world, int32_t srgb, kkd_mesh *out);
 
+/* The 'maxSmoothAngle' parameter of the mesh plugins (src/shapes/ply.cpp:124-128, serialized.cpp:204-208, obj.cpp:336-342):
+ * TriMesh::rebuildTopology (src/librender/trimesh.cpp:472-610) on a loaded mesh, in place -- vertices shared by faces whose
+ * normals differ by more than max_angle_deg are split, the others merged (keyed by position, uv and colour); stored normals
+ * are dropped, the caller regenerates them as TriMesh::configure does (trimesh.cpp:366-390).  Host only. */
+int kkd_mesh_rebuild_topology(kkd_mesh *mesh, float max_angle_deg);
+
 /* Releases the arrays of a loaded mesh (the reference frees them in TriMesh::~TriMesh, src/librender/trimesh.cpp:339-352). */
 void kkd_mesh_free(kkd_mesh *mesh);
 

@@ -443,3 +443,57 @@ def load_ply(path, to_world=None, srgb=True):
         col = np.where(c <= np.float32(0.04045), c / np.float32(12.92), ((c + np.float32(0.055)) / np.float32(1.0 + 0.055)) ** np.float32(2.4)).astype(np.float32)
     return {"name": os.path.splitext(os.path.basename(path))[0], "positions": pos, "normals": nrm, "texcoords": uv, "colors": col,
             "indices": np.array(tris, np.uint32), "face_normals": False}
+
+
+def rebuild_topology(mesh, max_angle_deg):
+    """TriMesh::rebuildTopology (reference src/librender/trimesh.cpp:472-610), the 'maxSmoothAngle' parameter of the mesh
+    plugins, corner by corner in float32 like the reference's Float (slow; small test meshes only).  mesh: dict as
+    load_serialized / load_ply return; -> new dict, normals dropped."""
+    pos = np.asarray(mesh["positions"], np.float32); idx = np.asarray(mesh["indices"], np.uint32)
+    uv = None if mesh.get("texcoords") is None else np.asarray(mesh["texcoords"], np.float32)
+    col = None if mesh.get("colors") is None else np.asarray(mesh["colors"], np.float32)
+    thresh = np.float32(np.cos(np.float32(max_angle_deg) * np.float32(np.pi / 180.0)))
+    face_n = np.zeros((len(idx), 3), np.float32)
+    entries = []                                    # multimap<Vertex, TopoData>: (key, insertion order) -> [tri, clustered]
+    for i, tri in enumerate(idx):
+        for j in range(3):
+            v = int(tri[j])
+            key = tuple(float(x) for x in pos[v]) + (tuple(float(x) for x in uv[v]) if uv is not None else (0.0, 0.0)) \
+                + (tuple(float(x) for x in col[v]) if col is not None else (0.0, 0.0, 0.0))
+            entries.append([key, len(entries), i, False])
+        a = pos[tri[1]] - pos[tri[0]]; b = pos[tri[2]] - pos[tri[0]]
+        n = np.array([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]], np.float32)
+        l = np.float32(np.sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]))
+        face_n[i] = n / l if l > np.float32(2.0 ** -128) else 0
+    entries.sort(key=lambda e: (e[0], e[1]))
+    new_pos, new_uv, new_col = [], [], []
+    new_idx = np.full((len(idx), 3), 0xFFFFFFFF, np.uint32)
+    start = 0
+    while start < len(entries):
+        end = start
+        while end < len(entries) and entries[end][0] == entries[start][0]:
+            end += 1
+        for i2 in range(start, end):
+            if entries[i2][3]:
+                continue
+            key = entries[i2][0]; n1 = face_n[entries[i2][2]]
+            vid = len(new_pos)
+            new_pos.append(key[0:3]); new_uv.append(key[3:5]); new_col.append(key[5:8])
+            for i3 in range(i2, end):
+                e = entries[i3]
+                if e[3]:
+                    continue
+                n2 = face_n[e[2]]
+                d = np.float32(np.float32(np.float32(n1[0] * n2[0]) + np.float32(n1[1] * n2[1])) + np.float32(n1[2] * n2[2]))
+                if np.array_equal(n1, n2) or d > thresh:
+                    for k in range(3):
+                        if tuple(float(x) for x in pos[idx[e[2], k]]) == key[0:3]:
+                            new_idx[e[2], k] = vid
+                    e[3] = True
+        start = end
+    assert (new_idx != 0xFFFFFFFF).all()
+    out = dict(mesh)
+    out["positions"] = np.array(new_pos, np.float32).reshape(-1, 3); out["indices"] = new_idx; out["normals"] = None
+    out["texcoords"] = None if uv is None else np.array(new_uv, np.float32).reshape(-1, 2)
+    out["colors"] = None if col is None else np.array(new_col, np.float32).reshape(-1, 3)
+    return out

@@ -491,4 +491,86 @@ int kkd_mesh_load_ply(const char *path, const float *to_world, int32_t srgb, kkd
     return KKD_OK;
 }
 
+/* TriMesh::rebuildTopology (src/librender/trimesh.cpp:472-610), what the 'maxSmoothAngle' parameter of the ply / serialized /
+ * obj plugins triggers (src/shapes/ply.cpp:124-128, serialized.cpp:204-208, obj.cpp:336-342): vertices are keyed by (position,
+ * uv, colour); the triangle corners that share a key are clustered greedily by their face normals -- a corner joins the
+ * cluster of the first unclustered corner n1 of its key when n1 == n2 or dot(n1, n2) > cos(maxAngle) -- and every cluster
+ * becomes one vertex of the new mesh; stored normals are dropped (the caller regenerates them as TriMesh::configure does).
+ * The reference walks a std::multimap<Vertex, TopoData>; equal keys keep insertion order there (triangle by triangle,
+ * corner by corner), which a stable sort of the corner list reproduces. */
+int kkd_mesh_rebuild_topology(kkd_mesh *m, float max_angle_deg) {
+    if (!m || !m->positions || !m->indices || m->n_tris == 0) return ioFail("kkd_mesh_rebuild_topology: empty mesh");
+    for (uint64_t i = 0; i < 3 * m->n_tris; ++i) if (m->indices[i] >= m->n_verts) return ioFail("kkd_mesh_rebuild_topology: vertex index out of range");
+    const float dpThresh = std::cos(max_angle_deg * (float)(M_PI / 180.0));            /* degToRad, trimesh.cpp:475 */
+    const bool hasUV = m->texcoords != nullptr, hasC = m->colors != nullptr;
+    struct Corner { float key[8]; uint32_t tri; bool clustered; };
+    const size_t nt = (size_t)m->n_tris;
+    std::vector<Corner> corners(3 * nt);
+    std::vector<float> faceN(3 * nt);
+    for (size_t i = 0; i < nt; ++i) {
+        const uint32_t *t = m->indices + 3 * i;
+        for (int j = 0; j < 3; ++j) {
+            Corner &c = corners[3 * i + j];
+            const float *p = m->positions + 3 * (size_t)t[j];
+            c.key[0] = p[0]; c.key[1] = p[1]; c.key[2] = p[2];
+            c.key[3] = hasUV ? m->texcoords[2 * (size_t)t[j]] : 0.f; c.key[4] = hasUV ? m->texcoords[2 * (size_t)t[j] + 1] : 0.f;
+            for (int k = 0; k < 3; ++k) c.key[5 + k] = hasC ? m->colors[3 * (size_t)t[j] + k] : 0.f;
+            c.tri = (uint32_t)i; c.clustered = false;
+        }
+        const float *v0 = m->positions + 3 * (size_t)t[0], *v1 = m->positions + 3 * (size_t)t[1], *v2 = m->positions + 3 * (size_t)t[2];
+        const float a[3] = { v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2] }, b[3] = { v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2] };
+        float n[3] = { a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0] };
+        const float l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        if (l > 0x1p-128f) { n[0] /= l; n[1] /= l; n[2] /= l; } else n[0] = n[1] = n[2] = 0.f;   /* RCPOVERFLOW_FLT: degenerate triangle */
+        faceN[3 * i] = n[0]; faceN[3 * i + 1] = n[1]; faceN[3 * i + 2] = n[2];
+    }
+    auto less = [](const Corner &x, const Corner &y) {                                   /* vertex_key_order, trimesh.cpp:437-460 */
+        for (int k = 0; k < 8; ++k) { if (x.key[k] < y.key[k]) return true; if (x.key[k] > y.key[k]) return false; }
+        return false;
+    };
+    std::stable_sort(corners.begin(), corners.end(), less);
+    std::vector<float> newPos, newUV, newCol;
+    newPos.reserve(3 * (size_t)m->n_verts);
+    std::vector<uint32_t> newIdx(3 * nt, 0xFFFFFFFFu);
+    for (size_t start = 0; start < corners.size();) {
+        size_t end = start + 1;
+        while (end < corners.size() && !less(corners[start], corners[end])) ++end;        /* equal range of the key */
+        for (size_t i2 = start; i2 < end; ++i2) {                                         /* greedy clustering of normals, :543-573 */
+            if (corners[i2].clustered) continue;
+            const float *n1 = &faceN[3 * (size_t)corners[i2].tri];
+            const uint32_t vertexIdx = (uint32_t)(newPos.size() / 3);
+            const float *key = corners[i2].key;
+            newPos.insert(newPos.end(), key, key + 3);
+            if (hasUV) newUV.insert(newUV.end(), key + 3, key + 5);
+            if (hasC) newCol.insert(newCol.end(), key + 5, key + 8);
+            for (size_t i3 = i2; i3 < end; ++i3) {
+                Corner &c2 = corners[i3];
+                if (c2.clustered) continue;
+                const float *n2 = &faceN[3 * (size_t)c2.tri];
+                const bool same = n1[0] == n2[0] && n1[1] == n2[1] && n1[2] == n2[2];
+                if (same || n1[0] * n2[0] + n1[1] * n2[1] + n1[2] * n2[2] > dpThresh) {
+                    const uint32_t *t = m->indices + 3 * (size_t)c2.tri;
+                    for (int k = 0; k < 3; ++k) {                                         /* every corner of that triangle AT this position, :566-569 */
+                        const float *p = m->positions + 3 * (size_t)t[k];
+                        if (p[0] == key[0] && p[1] == key[1] && p[2] == key[2]) newIdx[3 * (size_t)c2.tri + k] = vertexIdx;
+                    }
+                    c2.clustered = true;
+                }
+            }
+        }
+        start = end;
+    }
+    for (uint32_t v : newIdx) if (v == 0xFFFFFFFFu) return ioFail("kkd_mesh_rebuild_topology: a corner was left without a vertex");   /* Assert, :578-580 */
+    const size_t nv = newPos.size() / 3;
+    float *pos = allocArray<float>(3 * nv), *uv = hasUV ? allocArray<float>(2 * nv) : nullptr, *col = hasC ? allocArray<float>(3 * nv) : nullptr;
+    if (!pos || (hasUV && !uv) || (hasC && !col)) { std::free(pos); std::free(uv); std::free(col); g_globalError = "kkd_mesh_rebuild_topology: out of memory"; return KKD_ERR_NOMEM; }
+    std::memcpy(pos, newPos.data(), newPos.size() * sizeof(float));
+    if (hasUV) std::memcpy(uv, newUV.data(), newUV.size() * sizeof(float));
+    if (hasC) std::memcpy(col, newCol.data(), newCol.size() * sizeof(float));
+    std::memcpy(m->indices, newIdx.data(), newIdx.size() * sizeof(uint32_t));
+    std::free(m->positions); std::free(m->normals); std::free(m->texcoords); std::free(m->colors);
+    m->positions = pos; m->normals = nullptr; m->texcoords = uv; m->colors = col; m->n_verts = nv;
+    return KKD_OK;
+}
+
 } /* extern "C" */

@@ -294,21 +294,29 @@ def serialized_mesh_count(path):
     return int(n.value)
 
 
-def load_serialized(path, shape_index=0, to_world=None):
-    """The serialized shape plugin (reference src/shapes/serialized.cpp:150-206) through kkd_mesh_load_serialized."""
+def _smooth(lib, m, max_smooth_angle):
+    """'maxSmoothAngle' (reference src/shapes/ply.cpp:124-128, serialized.cpp:204-208): TriMesh::rebuildTopology on the loaded mesh"""
+    if max_smooth_angle is not None:
+        _io_check(lib.kkd_mesh_rebuild_topology(C.byref(m), float(max_smooth_angle)), "kkd_mesh_rebuild_topology")
+
+
+def load_serialized(path, shape_index=0, to_world=None, max_smooth_angle=None):
+    """The serialized shape plugin (reference src/shapes/serialized.cpp:150-208) through kkd_mesh_load_serialized."""
     lib = load_library(); m = abi.Mesh(); keep, ptr = _xf(to_world)
     _io_check(lib.kkd_mesh_load_serialized(os.fsencode(path), shape_index, ptr, C.byref(m)), "kkd_mesh_load_serialized")
     try:
+        _smooth(lib, m, max_smooth_angle)
         return _mesh_to_dict(m)
     finally:
         lib.kkd_mesh_free(C.byref(m))
 
 
-def load_ply(path, to_world=None, srgb=True):
+def load_ply(path, to_world=None, srgb=True, max_smooth_angle=None):
     """The ply shape plugin (reference src/shapes/ply.cpp:96-330) through kkd_mesh_load_ply."""
     lib = load_library(); m = abi.Mesh(); keep, ptr = _xf(to_world)
     _io_check(lib.kkd_mesh_load_ply(os.fsencode(path), ptr, int(srgb), C.byref(m)), "kkd_mesh_load_ply")
     try:
+        _smooth(lib, m, max_smooth_angle)
         return _mesh_to_dict(m)
     finally:
         lib.kkd_mesh_free(C.byref(m))

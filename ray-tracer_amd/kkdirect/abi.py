@@ -133,6 +133,7 @@ ENTRY_POINTS = {
     "kkd_mesh_load_serialized": (C.c_int, [C.c_char_p, i32, pf32, C.POINTER(Mesh)]),
     "kkd_mesh_save_serialized": (C.c_int, [C.c_char_p, C.POINTER(Mesh), u32]),
     "kkd_mesh_load_ply": (C.c_int, [C.c_char_p, pf32, i32, C.POINTER(Mesh)]),
+    "kkd_mesh_rebuild_topology": (C.c_int, [C.POINTER(Mesh), C.c_float]),
     "kkd_mesh_free": (None, [C.POINTER(Mesh)]),
     "kkd_request_cancel": (None, [C.c_void_p]),
     "kkd_set_progress_callback": (C.c_int, [C.c_void_p, PROGRESS_FN, C.c_void_p]),

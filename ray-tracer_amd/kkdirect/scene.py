@@ -139,15 +139,22 @@ class Scene:
                 nrm = -nrm
         return self.add_mesh(mesh["positions"], mesh["indices"], material, normals=nrm, texcoords=mesh["texcoords"], **kw)
 
-    def add_serialized(self, path, material, shape_index=0, to_world=None, face_normals=None, flip_normals=False, **kw):
-        """<shape type="serialized"> (reference src/shapes/serialized.cpp:150-206)."""
-        from . import load_serialized
-        return self.add_loaded_mesh(load_serialized(path, shape_index, to_world), material, face_normals, flip_normals, **kw)
+    @staticmethod
+    def _check_smooth(face_normals, max_smooth_angle):
+        if max_smooth_angle is not None and face_normals:      # ply.cpp:125-127, serialized.cpp:205-207
+            raise ValueError("The properties 'maxSmoothAngle' and 'faceNormals' can't be specified at the same time!")
 
-    def add_ply(self, path, material, to_world=None, srgb=True, face_normals=None, flip_normals=False, **kw):
+    def add_serialized(self, path, material, shape_index=0, to_world=None, face_normals=None, flip_normals=False, max_smooth_angle=None, **kw):
+        """<shape type="serialized"> (reference src/shapes/serialized.cpp:150-208)."""
+        from . import load_serialized
+        self._check_smooth(face_normals, max_smooth_angle)
+        return self.add_loaded_mesh(load_serialized(path, shape_index, to_world, max_smooth_angle), material, face_normals, flip_normals, **kw)
+
+    def add_ply(self, path, material, to_world=None, srgb=True, face_normals=None, flip_normals=False, max_smooth_angle=None, **kw):
         """<shape type="ply"> (reference src/shapes/ply.cpp:96-136)."""
         from . import load_ply
-        return self.add_loaded_mesh(load_ply(path, to_world, srgb), material, face_normals, flip_normals, **kw)
+        self._check_smooth(face_normals, max_smooth_angle)
+        return self.add_loaded_mesh(load_ply(path, to_world, srgb, max_smooth_angle), material, face_normals, flip_normals, **kw)
 
     def add_point_light(self, position, intensity, sampling_weight=1.0):
         e = abi.Emitter()

@@ -235,3 +235,61 @@ def test_render_scene_loaded_from_files(gpu, tmp_path):
         f2, _ = c2.render(8)
     # same samples, same scene; float atomics of neighbouring footprints commute only up to rounding
     assert f1[..., 4].sum() > 0 and np.allclose(f1, f2, rtol=1e-4, atol=1e-4)
+
+
+# ---- maxSmoothAngle: TriMesh::rebuildTopology (reference src/librender/trimesh.cpp:472-610) ---------------------------------
+def _cube_mesh(shared=True):
+    """a unit cube: 8 shared vertices / 12 triangles, or the same triangles with one private vertex per corner"""
+    p = np.array([[x, y, z] for x in (0, 1) for y in (0, 1) for z in (0, 1)], np.float32)
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    idx = np.array([t for a, b, c, d in quads for t in ((a, b, c), (a, c, d))], np.uint32)
+    if not shared:
+        p = p[idx.reshape(-1)]; idx = np.arange(36, dtype=np.uint32).reshape(12, 3)
+    return {"name": "cube", "positions": p, "indices": idx, "normals": None, "texcoords": None, "colors": None, "face_normals": False}
+
+
+@pytest.mark.parametrize("shared", [True, False])
+@pytest.mark.parametrize("angle,n_verts", [(30.0, 24), (100.0, 8)])
+def test_max_smooth_angle_on_a_cube(tmp_path, shared, angle, n_verts):
+    """The documented behaviour (reference src/shapes/obj.cpp:126-140): faces meeting at more than maxSmoothAngle get vertices of
+    their own (cube at 30 degrees: 6 faces x 4 corners), below it they share them (100 degrees: the 8 corners) -- whatever the
+    input's own sharing was."""
+    path = str(tmp_path / "cube.serialized")
+    kkdirect.save_serialized(path, [_cube_mesh(shared)])
+    got = kkdirect.load_serialized(path, max_smooth_angle=angle)
+    assert len(got["positions"]) == n_verts and got["normals"] is None and len(got["indices"]) == 12
+    src = _cube_mesh(shared)
+    np.testing.assert_array_equal(got["positions"][got["indices"]], src["positions"][src["indices"]])     # same triangles
+    if n_verts == 24:       # every vertex belongs to triangles of ONE face: its generated normal is the face normal
+        sc = Scene(); sc.add_serialized(path, sc.diffuse(), max_smooth_angle=angle)
+        pos, idx, nrm, _ = sc.arrays()
+        fn = np.cross(pos[idx[:, 1]] - pos[idx[:, 0]], pos[idx[:, 2]] - pos[idx[:, 0]]); fn /= np.linalg.norm(fn, axis=1, keepdims=True)
+        for k in range(3):
+            np.testing.assert_allclose(nrm[idx[:, k]], fn, atol=1e-6)
+
+
+@pytest.mark.parametrize("seed,uv,colors,angle", [(21, False, False, 20.0), (22, True, False, 12.0), (23, True, True, 60.0), (24, False, True, 5.0), (25, True, True, 0.5)])
+def test_max_smooth_angle_matches_the_restatement(tmp_path, seed, uv, colors, angle):
+    """library vs the oracle's corner-by-corner restatement on a bumpy grid with duplicated seam vertices (same positions,
+    other uv / colours), a degenerate triangle and a triangle that uses one vertex twice"""
+    m = _mesh(seed, n=8, normals=True, uv=uv, colors=colors)
+    m["positions"] = np.concatenate([m["positions"], m["positions"][:8]])                 # a seam: 8 positions a second time
+    for k in ("normals", "texcoords", "colors"):
+        if m[k] is not None:
+            extra = m[k][:8] if k == "normals" else np.random.RandomState(seed).rand(8, m[k].shape[1]).astype(np.float32)
+            m[k] = np.concatenate([m[k], extra])
+    n0 = 64
+    m["indices"] = np.concatenate([m["indices"], np.array([[n0, n0 + 1, 9], [n0 + 1, n0 + 2, 10], [3, 3, 12], [5, 5, 5]], np.uint32)])
+    path = str(tmp_path / "m.ply")
+    _write_ply(path, "le", m)
+    got = kkdirect.load_ply(path, max_smooth_angle=angle)
+    want = kkoracle.rebuild_topology(kkoracle.load_ply(path), angle)
+    _same(got, want)
+
+
+def test_max_smooth_angle_excludes_face_normals(tmp_path):
+    path = str(tmp_path / "cube.serialized")
+    kkdirect.save_serialized(path, [_cube_mesh()])
+    sc = Scene()
+    with pytest.raises(ValueError, match="maxSmoothAngle"):
+        sc.add_serialized(path, sc.diffuse(), face_normals=True, max_smooth_angle=30.0)
