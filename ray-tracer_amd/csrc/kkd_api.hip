@@ -637,6 +637,9 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         if (!report) return;
         const size_t k = (size_t)(index % kDoneRing);
         if (donePending[k]) { hipEventSynchronize(ctx->doneEvents[k]); pollProgress(false); }
+        /* with a listener the host stays at most four batches ahead of the device, so that reports arrive while the render runs
+         * (queueing a batch takes microseconds, running it milliseconds) */
+        if (index >= 4 && donePending[(size_t)((index - 4) % kDoneRing)]) { hipEventSynchronize(ctx->doneEvents[(size_t)((index - 4) % kDoneRing)]); pollProgress(false); }
         hipEventRecord(ctx->doneEvents[k], st); doneCount[k] = count; donePending[k] = true;
     };
     for (uint64_t w0 = 0; w0 < total; w0 += batch, ++batchIndex) {

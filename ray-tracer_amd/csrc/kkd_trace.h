@@ -215,7 +215,10 @@ struct Walk {
                 }
             }
             {
-                if (atLeaf) {
+                /* a lane whose node step just entered a leaf (nearest child, or popped) tests its first triangle in this same
+                 * iteration: the triangle code is issued anyway, so the step is free (C4 2759 -> 2862, C2 3227 -> 3293 Msamples/s).
+                 * Two node steps per iteration were measured as well: C4 2721, C2 3239. */
+                if ((cur & kLeafBit) && cur != kTraversalDone) {
                     const uint32_t slot = cur & kLeafStartMask;
                     if (COUNT) ++nTris;
                     const float4 *tp = tris4 + 3u * slot;   /* 32-bit shift-add, not a quarter-rate 64-bit multiply */

@@ -21,6 +21,10 @@ def golden():
 @pytest.fixture(scope="session")
 def gpu():
     """Session-wide check that the HIP library is loaded and a device is present; GPU tests fail loudly otherwise."""
+    try:
+        import torch   # noqa: F401 -- torch's HIP runtime has to be loaded before libkkdirect's, or torch later sees no device
+    except ImportError:
+        pass
     import kkdirect
     kkdirect.load_library()
     if kkdirect.device_count() < 1:
