@@ -115,7 +115,8 @@ typedef struct kkd_emitter {
 
 /* Environment map (emitters/envmap.cpp).  Texels are the level-0 MIP array, linear RGB float32,
  * row-major, row 0 = +Y pole (theta = 0).  The library rounds them to half precision like the
- * reference's TMIPMap<Spectrum, SpectrumHalf> storage (envmap.cpp:102-103). */
+ * reference's TMIPMap<Spectrum, SpectrumHalf> storage (envmap.cpp:102-103) and builds the MIP pyramid
+ * of the filtered lookup for camera rays (envmap.cpp:166-182, 394-407) at upload. */
 typedef struct kkd_envmap {
     uint32_t width, height;    /* 0,0 => no environment emitter                               */
     const float *texels;       /* width*height*3                                              */

@@ -80,7 +80,7 @@ int ora_li_samples(ora_ctx *c, const kkd_render_params *p, uint64_t seed, const 
         SampleStream rng(seed, (uint32_t)(((int)Y + edge) * (W + 2 * edge) + ((int)X + edge)), s);
         V2 jit = rng.next2D();
         V2 sp{ (Float)X + jit.x, (Float)Y + jit.y };
-        Ray ray = c->scene.sensor.sampleRay(sp);
+        Ray ray = c->scene.sensor.sampleRay(sp, 1.0f / std::sqrt((Float)rp.spp));
         Float alpha = 1.0f;
         V3 L = c->scene.Li(ray, rng, rp, alpha, nullptr);
         float *o = out + 6 * i; o[0] = L.x; o[1] = L.y; o[2] = L.z; o[3] = alpha; o[4] = sp.x; o[5] = sp.y;

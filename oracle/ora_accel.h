@@ -65,6 +65,8 @@ struct AABB {
 
 struct Ray {
     V3 o, d, dRcp; Float mint, maxt;
+    /* RayDifferential (ray.h, absent): only the direction offsets are used on this path (envmap.cpp:394-407) */
+    bool hasDifferentials = false; V3 rxDirection, ryDirection;
     Ray() {}
     Ray(V3 o_, V3 d_, Float mint_, Float maxt_) : o(o_), d(d_), mint(mint_), maxt(maxt_) {
         dRcp = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);

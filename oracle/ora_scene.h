@@ -19,8 +19,9 @@
  * mipmap.h evalBilinear/evalTexel) are restated from SURVEY.md 9.3-9.5: parity unpinned except for
  * the hit-record vectors of tests/test_dgeom.cpp:35-120.
  *
- * Documented deviation: primary-ray environment lookups use the bilinear level-0 texel fetch instead
- * of the EWA-filtered MIP lookup with ray differentials (envmap.cpp:394-407; TMIPMap is absent).
+ * Primary-ray environment lookups are the EWA-filtered MIP lookup with ray differentials (envmap.cpp:394-407); TMIPMap and
+ * Resampler live in headers the checkout does not hold (mipmap.h, rfilter.h): restated from the published Mitsuba 0.5 sources,
+ * parity unpinned.
  */
 #pragma once
 #include "ora_accel.h"
@@ -224,8 +225,160 @@ struct EmitterRec { int type, shape; Float weight; V3 radiance, position; };
 /* DirectSamplingRecord (records.inl, absent) */
 struct DirectRec { V3 ref, refN, p, n, d; Float dist, pdf; int measure; /* 0 solid angle, 1 discrete */ int emitter; };
 
+/* Resampler (rfilter.h, absent from the checkout: restated from the published Mitsuba 0.5 header; parity unpinned) with the
+ * 2-lobed Lanczos filter of rfilters/lanczos.cpp, as envmap.cpp:166-172 configures it.  repeat: ERepeat, else EClamp. */
+struct Resampler {
+    int sourceRes, targetRes, taps; std::vector<int> start; std::vector<Float> weights; bool repeat;
+    static Float lanczos2(Float x) {
+        x = std::fabs(x);
+        if (x < kEpsilon) return 1.0f; else if (x > 2.0f) return 0.0f;
+        Float x1 = kPi * x, x2 = x1 / 2.0f;
+        return (std::sin(x1) * std::sin(x2)) / (x1 * x2);
+    }
+    Resampler(bool repeat_, int src, int trg) : sourceRes(src), targetRes(trg), repeat(repeat_) {
+        Float filterRadius = 2.0f, scale = 1.0f, invScale = 1.0f;
+        if (trg < src) { scale = (Float)src / (Float)trg; invScale = 1 / scale; filterRadius *= scale; }
+        taps = (int)std::ceil(filterRadius * 2);
+        start.resize(trg); weights.resize((size_t)taps * trg);
+        for (int i = 0; i < trg; ++i) {
+            Float center = (i + (Float)0.5f) / trg * src;
+            start[i] = (int)std::floor(center - filterRadius + (Float)0.5f);
+            Float sum = 0;
+            for (int j = 0; j < taps; ++j) {
+                Float pos = start[i] + j + (Float)0.5f - center;
+                Float weight = lanczos2(pos * invScale);
+                weights[(size_t)i * taps + j] = weight; sum += weight;
+            }
+            Float normalization = 1.0f / sum;
+            for (int j = 0; j < taps; ++j) weights[(size_t)i * taps + j] *= normalization;
+        }
+    }
+    /* resampleAndClamp over one line of V3 with the given strides, clamped to [0, inf) */
+    void run(const V3 *src, size_t srcStride, V3 *trg, size_t trgStride) const {
+        for (int i = 0; i < targetRes; ++i) {
+            V3 result(0.f);
+            for (int j = 0; j < taps; ++j) {
+                int pos = start[i] + j;
+                if (pos < 0 || pos >= sourceRes) {
+                    if (repeat) { pos %= sourceRes; if (pos < 0) pos += sourceRes; }
+                    else pos = std::min(std::max(pos, 0), sourceRes - 1);
+                }
+                result += src[(size_t)pos * srcStride] * weights[(size_t)i * taps + j];
+            }
+            trg[(size_t)i * trgStride] = V3(std::max(result.x, 0.0f), std::max(result.y, 0.0f), std::max(result.z, 0.0f));
+        }
+    }
+};
+
 struct EnvMap {
     int w = 0, h = 0; std::vector<V3> texels; Float scale = 1;
+    /* TMIPMap (mipmap.h, absent: restated from the published Mitsuba 0.5 header; parity unpinned): level 0 = texels, every
+     * further level half the size (rounded up), resampled from the unquantised level before and stored as half */
+    struct Level { int w, h; std::vector<V3> texels; };
+    std::vector<Level> pyramid;                /* levels 1 ... */
+    Float weightLut[64];
+    int levels() const { return 1 + (int)pyramid.size(); }
+    void buildPyramid(const std::vector<V3> &level0Float) {
+        for (int i = 0; i < 64; ++i) { Float r2 = (Float)i / (Float)63; weightLut[i] = std::exp(-2.0f * r2) - std::exp(-2.0f); }
+        std::vector<V3> cur = level0Float; int cw = w, ch = h;
+        while (cw > 1 || ch > 1) {
+            const int nw = std::max(1, (cw + 1) / 2), nh = std::max(1, (ch + 1) / 2);
+            std::vector<V3> tmp((size_t)nw * ch), nxt((size_t)nw * nh);
+            if (nw != cw) { Resampler r(true, cw, nw); for (int y = 0; y < ch; ++y) r.run(&cur[(size_t)y * cw], 1, &tmp[(size_t)y * nw], 1); }
+            else tmp = cur;
+            if (nh != ch) { Resampler r(false, ch, nh); for (int x = 0; x < nw; ++x) r.run(&tmp[x], nw, &nxt[x], nw); }
+            else nxt = tmp;
+            Level L; L.w = nw; L.h = nh; L.texels.resize(nxt.size());
+            for (size_t i = 0; i < nxt.size(); ++i) L.texels[i] = V3(roundToHalf(nxt[i].x), roundToHalf(nxt[i].y), roundToHalf(nxt[i].z));
+            pyramid.push_back(std::move(L));
+            cur.swap(nxt); cw = nw; ch = nh;
+        }
+    }
+    V3 texelL(int level, int x, int y) const {
+        if (level == 0) return texel(x, y);
+        const Level &L = pyramid[level - 1];
+        x = x % L.w; if (x < 0) x += L.w;
+        y = std::min(std::max(y, 0), L.h - 1);
+        return L.texels[(size_t)y * L.w + x];
+    }
+    void sizeL(int level, int &lw, int &lh) const { if (level == 0) { lw = w; lh = h; } else { lw = pyramid[level - 1].w; lh = pyramid[level - 1].h; } }
+    /* mipmap.h evalBilinear(level, uv) */
+    V3 evalBilinear(int level, V2 uv) const {
+        if (!std::isfinite(uv.x) || !std::isfinite(uv.y)) return V3(0.f);
+        int lw, lh;
+        if (level >= levels()) {                      /* evalBox on the coarsest level */
+            sizeL(levels() - 1, lw, lh);
+            return texelL(levels() - 1, (int)std::floor(uv.x * lw), (int)std::floor(uv.y * lh));
+        }
+        sizeL(level, lw, lh);
+        Float u = uv.x * lw - 0.5f, v = uv.y * lh - 0.5f;
+        int xPos = (int)std::floor(u), yPos = (int)std::floor(v);
+        Float dx1 = u - xPos, dx2 = 1.0f - dx1, dy1 = v - yPos, dy2 = 1.0f - dy1;
+        return texelL(level, xPos, yPos) * dx2 * dy2 + texelL(level, xPos, yPos + 1) * dx2 * dy1
+             + texelL(level, xPos + 1, yPos) * dx1 * dy2 + texelL(level, xPos + 1, yPos + 1) * dx1 * dy1;
+    }
+    /* mipmap.h evalEWA */
+    V3 evalEWA(int level, V2 uv, Float A, Float B, Float C) const {
+        if (!std::isfinite(A + B + C + uv.x + uv.y)) return V3(0.f);
+        if (level >= levels()) return evalBilinear(level, uv);
+        int lw, lh; sizeL(level, lw, lh);
+        Float u = uv.x * lw - 0.5f, v = uv.y * lh - 0.5f;
+        Float ratio0 = lw / (Float)w, ratio1 = lh / (Float)h;
+        A /= ratio0 * ratio0; B /= ratio0 * ratio1; C /= ratio1 * ratio1;
+        Float invDet = 1.0f / (-B * B + 4.0f * A * C), deltaU = 2.0f * std::sqrt(C * invDet), deltaV = 2.0f * std::sqrt(A * invDet);
+        int u0 = (int)std::ceil(u - deltaU), u1 = (int)std::floor(u + deltaU);
+        int v0 = (int)std::ceil(v - deltaV), v1 = (int)std::floor(v + deltaV);
+        Float As = A * 64, Bs = B * 64, Cs = C * 64;
+        V3 result(0.f); Float denominator = 0.0f;
+        Float ddq = 2 * As, uu0 = (Float)u0 - u;
+        for (int vt = v0; vt <= v1; ++vt) {
+            const Float vv = (Float)vt - v;
+            Float q = As * uu0 * uu0 + (Bs * uu0 + Cs * vv) * vv;
+            Float dq = As * (2 * uu0 + 1) + Bs * vv;
+            for (int ut = u0; ut <= u1; ++ut) {
+                if (q < (Float)64) {
+                    uint32_t qi = (uint32_t)q;
+                    if (qi < 64) {
+                        const Float weight = weightLut[(int)q];
+                        result += texelL(level, ut, vt) * weight;
+                        denominator += weight;
+                    }
+                }
+                q += dq; dq += ddq;
+            }
+        }
+        if (denominator == 0) return evalBilinear(level, uv);
+        return result / denominator;
+    }
+    /* mipmap.h eval(uv, d0, d1): EWA filter type, maxAnisotropy 10 (envmap.cpp:141-142) */
+    V3 evalFiltered(V2 uv, V2 d0, V2 d1) const {
+        const Float maxAnisotropy = 10.0f;
+        Float du0 = d0.x * w, dv0 = d0.y * h, du1 = d1.x * w, dv1 = d1.y * h;
+        Float A = dv0 * dv0 + dv1 * dv1, B = -2.0f * (du0 * dv0 + du1 * dv1), C = du0 * du0 + du1 * du1, F = A * C - B * B * 0.25f;
+        Float root = std::hypot(A - C, B), Aprime = 0.5f * (A + C - root), Cprime = 0.5f * (A + C + root),
+              majorRadius = Aprime != 0 ? std::sqrt(F / Aprime) : 0, minorRadius = Cprime != 0 ? std::sqrt(F / Cprime) : 0;
+        if (!(minorRadius > 0) || !(majorRadius > 0) || F < 0) {
+            Float level = std::log2(std::max(majorRadius, kEpsilon));
+            int ilevel = (int)std::floor(level);
+            if (ilevel < 0) return evalBilinear(0, uv);
+            Float a = level - ilevel;
+            return evalBilinear(ilevel, uv) * (1.0f - a) + evalBilinear(ilevel + 1, uv) * a;
+        }
+        if (minorRadius * maxAnisotropy < majorRadius) {
+            minorRadius = majorRadius / maxAnisotropy;
+            Float theta = 0.5f * std::atan(B / (A - C)), sinTheta = std::sin(theta), cosTheta = std::cos(theta);
+            Float a2 = majorRadius * majorRadius, b2 = minorRadius * minorRadius, sinTheta2 = sinTheta * sinTheta, cosTheta2 = cosTheta * cosTheta,
+                  sin2Theta = 2 * sinTheta * cosTheta;
+            A = a2 * cosTheta2 + b2 * sinTheta2; B = (a2 - b2) * sin2Theta; C = a2 * sinTheta2 + b2 * cosTheta2; F = a2 * b2;
+        }
+        Float sc = 1.0f / F;
+        A *= sc; B *= sc; C *= sc;
+        Float level = std::max((Float)0.0f, std::log2(minorRadius));
+        int ilevel = (int)level;
+        Float a = level - ilevel;
+        if (majorRadius < 1 || !(A > 0 && C > 0)) return evalBilinear(ilevel, uv);
+        return evalEWA(ilevel, uv, A, B, C) * (1.0f - a) + evalEWA(ilevel + 1, uv, A, B, C) * a;
+    }
     Float toWorld[9], toLocal[9];
     V3 center; Float radius = 0;
     std::vector<float> cdfRows, cdfCols; std::vector<Float> rowWeights; Float normalization = 0; V2 pixelSize;
@@ -312,6 +465,16 @@ struct EnvMap {
                  + texel(xPos + 1, yPos) * dx1 * dy2 + texel(xPos + 1, yPos + 1) * dx1 * dy1;
         return value * scale;
     }
+    /* envmap.cpp:379-409: the filtered lookup for a ray with differentials (the primary ray) */
+    V3 evalEnvironment(const Ray &ray) const {
+        if (!ray.hasDifferentials) return evalEnvironment(ray.d);
+        V3 v = rot(toLocal, ray.d);
+        V2 uv{ std::atan2(v.x, -v.z) * kInvTwoPi, safe_acos(v.y) * kInvPi };
+        V3 dvdx = rot(toLocal, ray.rxDirection) - v, dvdy = rot(toLocal, ray.ryDirection) - v;
+        Float t1 = kInvTwoPi / (v.x * v.x + v.z * v.z), t2 = -kInvPi / std::max(safe_sqrt(1.0f - v.y * v.y), kEpsilon);
+        V2 dudx{ t1 * (dvdx.z * v.x - dvdx.x * v.z), t2 * dvdx.y }, dudy{ t1 * (dvdy.z * v.x - dvdy.x * v.z), t2 * dvdy.y };
+        return evalFiltered(uv, dudx, dudy) * scale;
+    }
 };
 
 struct Sensor {
@@ -333,12 +496,16 @@ struct Sensor {
         dx = sampleToCamera.point(V3(invRes.x, 0, 0)) - sampleToCamera.point(V3(0.f));
         dy = sampleToCamera.point(V3(0, invRes.y, 0)) - sampleToCamera.point(V3(0.f));
     }
-    /* perspective.cpp:271-298 (differentials unused on this path, see header) */
-    Ray sampleRay(V2 pixelSample) const {
+    /* perspective.cpp:271-298 + RayDifferential::scaleDifferential (integrator.cpp:181; ray.h absent: d + (rxDirection - d) * amount) */
+    Ray sampleRay(V2 pixelSample, Float diffScale = 1.0f) const {
         V3 nearP = sampleToCamera.point(V3(pixelSample.x * invRes.x, pixelSample.y * invRes.y, 0.0f));
         V3 d = normalize(nearP);
         Float invZ = 1.0f / d.z;
-        return Ray(toWorld.pointAffine(V3(0.f)), toWorld.vector(d), nearClip * invZ, farClip * invZ);
+        Ray ray(toWorld.pointAffine(V3(0.f)), toWorld.vector(d), nearClip * invZ, farClip * invZ);
+        ray.rxDirection = toWorld.vector(normalize(nearP + dx)); ray.ryDirection = toWorld.vector(normalize(nearP + dy));
+        ray.rxDirection = ray.d + (ray.rxDirection - ray.d) * diffScale; ray.ryDirection = ray.d + (ray.ryDirection - ray.d) * diffScale;
+        ray.hasDifferentials = true;
+        return ray;
     }
 };
 
@@ -518,7 +685,7 @@ inline V3 Scene::Li(const Ray &ray, SampleStream &rng, const RenderParams &rp, F
     Hit hit;
     if (!rayIntersect(ray, hit, st)) {                     /* :55-60 */
         if (filmHasAlpha) alpha = 0;
-        if (!rp.hideEmitters && envEmitter >= 0) return env.evalEnvironment(ray.d);
+        if (!rp.hideEmitters && envEmitter >= 0) return env.evalEnvironment(ray);
         return V3(0.f);
     }
     Intersection its; fillIntersection(ray, hit, its);
@@ -662,7 +829,7 @@ inline V3 Scene::LiPath(const Ray &r, SampleStream &rng, const RenderParams &rp,
     ray.mint = kEpsilon;
     while (depth <= rp.maxDepth || rp.maxDepth < 0) {                                    /* :135 */
         if (!valid) {                                                                    /* :136-143 */
-            if (emitted && (!rp.hideEmitters || scattered) && envEmitter >= 0) Li += throughput * env.evalEnvironment(ray.d);
+            if (emitted && (!rp.hideEmitters || scattered) && envEmitter >= 0) Li += throughput * env.evalEnvironment(ray);   /* differentials: the primary ray only */
             break;
         }
         const ShapeRec &shape = shapes[its.shape];
@@ -763,7 +930,7 @@ inline void Scene::render(const RenderParams &rp, float *film, Stats *st, int nT
                     SampleStream rng(rp.seed, (uint32_t)((Y + edge) * EW + (X + edge)), rp.sampleFirst + j);
                     V2 jit = rng.next2D();
                     V2 samplePos{ (Float)X + jit.x, (Float)Y + jit.y };
-                    Ray ray = sensor.sampleRay(samplePos);
+                    Ray ray = sensor.sampleRay(samplePos, 1.0f / std::sqrt((Float)rp.spp));   /* integrator.cpp:144-145, 181 */
                     Float alpha = 1.0f;
                     V3 spec = Li(ray, rng, rp, alpha, st);
                     if (st) st->samples++;
@@ -888,8 +1055,12 @@ inline bool Scene::load(const kkd_scene_desc *sd, std::string &err) {
         if (!k.width || !k.height || !k.texels) { err = "envmap emitter without texels"; return false; }
         env.w = (int)k.width; env.h = (int)k.height; env.scale = k.scale;
         env.texels.resize((size_t)env.w * env.h);
-        for (size_t i = 0; i < env.texels.size(); ++i)
+        std::vector<V3> level0(env.texels.size());
+        for (size_t i = 0; i < env.texels.size(); ++i) {
+            level0[i] = V3(k.texels[3 * i], k.texels[3 * i + 1], k.texels[3 * i + 2]);
             env.texels[i] = V3(roundToHalf(k.texels[3 * i]), roundToHalf(k.texels[3 * i + 1]), roundToHalf(k.texels[3 * i + 2]));
+        }
+        env.buildPyramid(level0);
         for (int i = 0; i < 9; ++i) env.toWorld[i] = k.to_world[i];
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) env.toLocal[3 * i + j] = k.to_world[3 * j + i];
         env.center = V3(k.bsphere_center[0], k.bsphere_center[1], k.bsphere_center[2]); env.radius = k.bsphere_radius;

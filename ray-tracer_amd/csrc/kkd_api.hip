@@ -85,7 +85,7 @@ struct kkd_ctx {
     DScene ds{};
     /* scene buffers */
     DevBuf nodes, wideNodes, tris, projTris, positions, normals, texcoords, indices, shapes, materials, emitters, emitterCdf, emitterGuide, areaGuide, areaCdf, rtTables,
-           envTexels, envCdfRows, envCdfCols, envRowWeights, envGuideRows, envGuideCols;
+           envTexels, envCdfRows, envCdfCols, envRowWeights, envGuideRows, envGuideCols, envEwaLut;
     /* work buffers */
     DevBuf contRecs, contStacks, contCount, pathAlive, pBsdfRays, pBrec, pRefN, pShadowRays, pLrec, pSampleIdx;
     /* first-round step budgets of the round-based traversal; adapted from the share of rays the last batch parked */
@@ -178,7 +178,7 @@ void kkd_destroy(kkd_ctx *ctx) {
                       &ctx->emitters, &ctx->emitterCdf, &ctx->areaCdf, &ctx->rtTables, &ctx->envTexels, &ctx->envCdfRows, &ctx->envCdfCols,
                       &ctx->envRowWeights, &ctx->contRecs, &ctx->contStacks, &ctx->contCount, &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->shadowRays,
                       &ctx->occluded, &ctx->lrec, &ctx->film, &ctx->counters, &ctx->apiRays, &ctx->apiHits,
-                      &ctx->envGuideRows, &ctx->envGuideCols, &ctx->emitterGuide, &ctx->areaGuide, &ctx->pathAlive, &ctx->pBsdfRays, &ctx->pBrec, &ctx->pRefN, &ctx->pShadowRays, &ctx->pLrec, &ctx->pSampleIdx, &ctx->tileList };
+                      &ctx->envGuideRows, &ctx->envGuideCols, &ctx->emitterGuide, &ctx->areaGuide, &ctx->pathAlive, &ctx->pBsdfRays, &ctx->pBrec, &ctx->pRefN, &ctx->pShadowRays, &ctx->pLrec, &ctx->pSampleIdx, &ctx->tileList, &ctx->envEwaLut };
     for (DevBuf *b : all) b->release();
     for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->doneEvents) hipEventDestroy(ev);
@@ -235,6 +235,7 @@ static int uploadHostScene(kkd_ctx *ctx, const HostScene &hs, const kkd_scene_de
     UP(envRowWeights, hs.envRowWeights.data(), hs.envRowWeights.size())
     UP(envGuideRows, hs.envGuideRows.data(), hs.envGuideRows.size())
     UP(envGuideCols, hs.envGuideCols.data(), hs.envGuideCols.size())
+    UP(envEwaLut, hs.envEwaLut.data(), hs.envEwaLut.size())
 #undef UP
     KKD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     BVH4::Info accel = hs.bvh.info;
@@ -275,6 +276,7 @@ static int uploadHostScene(kkd_ctx *ctx, const HostScene &hs, const kkd_scene_de
     d.env.texels = (const uint32_t *)ctx->envTexels.p; d.env.cdfRows = (const float *)ctx->envCdfRows.p;
     d.env.cdfCols = (const float *)ctx->envCdfCols.p; d.env.rowWeights = (const float *)ctx->envRowWeights.p;
     d.env.guideRows = (const uint32_t *)ctx->envGuideRows.p; d.env.guideCols = (const uint32_t *)ctx->envGuideCols.p;
+    d.env.ewaLut = (const float *)ctx->envEwaLut.p;
     d.sensor = hs.sensor; d.filter = hs.filter;
     ctx->accelInfo = accel;
     ctx->tileKey[3] = 0;            /* a new film / tile grid: the cached tile list is stale */
@@ -583,6 +585,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     bp.seed = ctx->cfg.seed; bp.stride = (uint32_t)S;
     bp.g = g; bp.gShift = gShift; bp.chunks = chunks; bp.spp = rp->spp; bp.sampleFirst = rp->sample_first;
     bp.nB = nB; bp.nL = nL; bp.hideEmitters = rp->hide_emitters != 0;
+    bp.diffScale = 1.0f / std::sqrt((float)rp->spp);
     bp.integrator = rp->integrator; bp.strictNormals = rp->strict_normals != 0;
     bp.maxDepth = rp->max_depth; bp.rrDepth = rp->rr_depth; bp.depth = 1;
     bp.chunksShift = 32; bp.pixShift = 32;

@@ -21,7 +21,9 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <tuple>
 
 namespace kkd {
@@ -254,6 +256,89 @@ static bool mat4inv(const double m[16], double out[16]) {
 
 #define KKD_FAIL(code, msg) do { err = (msg); if (errCode) *errCode = (code); return false; } while (0)
 
+/* MIP pyramid of the environment map: what TMIPMap's constructor builds for envmap.cpp:166-182 -- every level half the size
+ * of the one before (rounded up), resampled along x (repeat) and then y (clamp) as Bitmap::resample does (bitmap.cpp:2221-2320)
+ * with the 2-lobed Lanczos filter (rfilters/lanczos.cpp), clamped to [0, inf), from the unquantised level before, stored as
+ * half.  TMIPMap and Resampler live in headers the checkout does not hold (mipmap.h, rfilter.h): restated from the published
+ * Mitsuba 0.5 sources, parity unpinned. */
+namespace {
+struct LineResampler {
+    int sourceRes, targetRes, taps; bool repeat; std::vector<int> start; std::vector<float> weights;
+    static float lanczos2(float x) {
+        x = std::fabs(x);
+        if (x < 1e-4f) return 1.0f; else if (x > 2.0f) return 0.0f;
+        const float x1 = kPi * x, x2 = x1 / 2.0f;
+        return (std::sin(x1) * std::sin(x2)) / (x1 * x2);
+    }
+    LineResampler(bool rep, int src, int trg) : sourceRes(src), targetRes(trg), repeat(rep) {
+        float filterRadius = 2.0f, invScale = 1.0f;
+        if (trg < src) { const float scale = (float)src / (float)trg; invScale = 1 / scale; filterRadius *= scale; }
+        taps = (int)std::ceil(filterRadius * 2);
+        start.resize(trg); weights.resize((size_t)taps * trg);
+        for (int i = 0; i < trg; ++i) {
+            const float center = (i + 0.5f) / trg * src;
+            start[i] = (int)std::floor(center - filterRadius + 0.5f);
+            float sum = 0;
+            for (int j = 0; j < taps; ++j) { const float wgt = lanczos2((start[i] + j + 0.5f - center) * invScale); weights[(size_t)i * taps + j] = wgt; sum += wgt; }
+            const float normalization = 1.0f / sum;
+            for (int j = 0; j < taps; ++j) weights[(size_t)i * taps + j] *= normalization;
+        }
+    }
+    void run(const float *src, size_t srcStride, float *trg, size_t trgStride) const {   /* strides in RGB triples */
+        for (int i = 0; i < targetRes; ++i) {
+            float r[3] = { 0.f, 0.f, 0.f };
+            for (int j = 0; j < taps; ++j) {
+                int pos = start[i] + j;
+                if (pos < 0 || pos >= sourceRes) {
+                    if (repeat) { pos %= sourceRes; if (pos < 0) pos += sourceRes; }
+                    else pos = std::min(std::max(pos, 0), sourceRes - 1);
+                }
+                const float wgt = weights[(size_t)i * taps + j], *sp = src + (size_t)pos * srcStride * 3;
+                /* (x + y * w) with separate roundings, as the oracle's vector arithmetic does */
+                for (int c = 0; c < 3; ++c) { const float prod = sp[c] * wgt; r[c] = r[c] + prod; }
+            }
+            for (int c = 0; c < 3; ++c) trg[(size_t)i * trgStride * 3 + c] = std::max(r[c], 0.0f);
+        }
+    }
+};
+}
+static void parallelLines(size_t n, const std::function<void(size_t)> &f) {
+    const size_t nThreads = std::min<size_t>(std::max(1u, std::min(std::thread::hardware_concurrency(), 16u)), std::max<size_t>(1, n / 64));
+    if (nThreads <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < nThreads; ++t) pool.emplace_back([&, t] { for (size_t i = n * t / nThreads, e = n * (t + 1) / nThreads; i < e; ++i) f(i); });
+    for (auto &th : pool) th.join();
+}
+static void buildEnvPyramid(const float *level0, int w, int h, HostScene &hs) {
+    hs.envEwaLut.resize(64);
+    for (int i = 0; i < 64; ++i) { const float r2 = (float)i / 63.0f; hs.envEwaLut[i] = std::exp(-2.0f * r2) - std::exp(-2.0f); }
+    hs.env.nLevels = 1; hs.env.levelOfs[0] = 0; hs.env.levelW[0] = (uint16_t)w; hs.env.levelH[0] = (uint16_t)h;
+    std::vector<float> cur(level0, level0 + (size_t)w * h * 3), tmp, nxt;
+    int cw = w, ch = h;
+    while (cw > 1 || ch > 1) {
+        const int nw = std::max(1, (cw + 1) / 2), nh = std::max(1, (ch + 1) / 2);
+        if (nw != cw) {
+            tmp.assign((size_t)nw * ch * 3, 0.f);
+            const LineResampler r(true, cw, nw);
+            parallelLines((size_t)ch, [&](size_t y) { r.run(&cur[y * cw * 3], 1, &tmp[y * nw * 3], 1); });
+        } else tmp = cur;
+        if (nh != ch) {
+            nxt.assign((size_t)nw * nh * 3, 0.f);
+            const LineResampler r(false, ch, nh);
+            parallelLines((size_t)nw, [&](size_t x) { r.run(&tmp[x * 3], (size_t)nw, &nxt[x * 3], (size_t)nw); });
+        } else nxt = tmp;
+        const int l = hs.env.nLevels++;
+        const size_t ofs = hs.envTexels.size() / 4;
+        hs.env.levelOfs[l] = (uint32_t)ofs; hs.env.levelW[l] = (uint16_t)nw; hs.env.levelH[l] = (uint16_t)nh;
+        hs.envTexels.resize((ofs + (size_t)nw * nh) * 4);
+        for (size_t i = 0; i < (size_t)nw * nh; ++i) {
+            for (int c = 0; c < 3; ++c) hs.envTexels[(ofs + i) * 4 + c] = floatToHalf(nxt[i * 3 + c]);
+            hs.envTexels[(ofs + i) * 4 + 3] = 0;
+        }
+        cur.swap(nxt); cw = nw; ch = nh;
+    }
+}
+
 bool flattenScene(const kkd_scene_desc *sd, HostScene &hs, std::string &err, int *errCode, bool buildBvh) {
     if (!sd) KKD_FAIL(KKD_ERR_INVALID, "scene description is NULL");
     if (sd->abi_version != KKD_ABI_VERSION) KKD_FAIL(KKD_ERR_INVALID, "scene description has a different ABI version");
@@ -467,6 +552,7 @@ bool flattenScene(const kkd_scene_desc *sd, HostScene &hs, std::string &err, int
             hs.envGuideCols.resize((size_t)h * (kEnvGuideCols + 1));
             for (int y = 0; y < h; ++y) guide(hs.envCdfCols.data() + (size_t)y * (w + 1), (size_t)w + 1, kEnvGuideCols, hs.envGuideCols.data() + (size_t)y * (kEnvGuideCols + 1));
         }
+        buildEnvPyramid(k.texels, w, h, hs);
         hs.env.normalization = 1.0f / (rowSum * (2 * kPi / w) * (kPi / h));
         hs.env.pixelSizeX = 2 * kPi / w; hs.env.pixelSizeY = kPi / h;
         for (int i = 0; i < 9; ++i) hs.env.toWorld[i] = k.to_world[i];
@@ -497,6 +583,16 @@ bool flattenScene(const kkd_scene_desc *sd, HostScene &hs, std::string &err, int
         if (!mat4inv(c2s, s2c)) KKD_FAIL(KKD_ERR_INVALID, "singular camera projection");
         for (int i = 0; i < 16; ++i) hs.sensor.s2c[i] = (float)s2c[i];
         for (int i = 0; i < 12; ++i) hs.sensor.toWorld[i] = s.to_world[i];
+        {   /* m_dx, m_dy (perspective.cpp:159-163): sampleToCamera applied to points, in single precision like the ray itself */
+            const float *m = hs.sensor.s2c;
+            auto point = [&](float x, float y, float out[3]) {
+                const float cx = m[0] * x + m[1] * y + m[3], cy = m[4] * x + m[5] * y + m[7], cz = m[8] * x + m[9] * y + m[11], cw = m[12] * x + m[13] * y + m[15];
+                if (cw == 1.0f) { out[0] = cx; out[1] = cy; out[2] = cz; } else { out[0] = cx / cw; out[1] = cy / cw; out[2] = cz / cw; }
+            };
+            float p0[3], px[3], py[3];
+            point(0.f, 0.f, p0); point(1.0f / (float)s.crop_width, 0.f, px); point(0.f, 1.0f / (float)s.crop_height, py);
+            for (int c = 0; c < 3; ++c) { hs.sensor.dxCam[c] = px[c] - p0[c]; hs.sensor.dyCam[c] = py[c] - p0[c]; }
+        }
         hs.sensor.nearClip = s.near_clip; hs.sensor.farClip = s.far_clip;
         hs.sensor.invResX = 1.0f / (float)s.crop_width; hs.sensor.invResY = 1.0f / (float)s.crop_height;
         hs.sensor.cropW = (int)s.crop_width; hs.sensor.cropH = (int)s.crop_height; hs.sensor.filmHasAlpha = s.film_has_alpha != 0; hs.sensor.hqEdges = s.film_high_quality_edges != 0;

@@ -27,7 +27,8 @@ struct HostScene {
     float emitterNormalization = 0.f;
     /* envmap */
     DEnvMap env{};                   /* pointer members filled after upload */
-    std::vector<uint16_t> envTexels; /* RGBA half */
+    std::vector<uint16_t> envTexels; /* RGBA half, all MIP levels back to back */
+    std::vector<float> envEwaLut;
     std::vector<float> envCdfRows, envCdfCols, envRowWeights;
     std::vector<uint32_t> envGuideRows, envGuideCols;
     DSensor sensor{};

@@ -23,6 +23,7 @@ struct BatchParams {
      * group(w0) = (tile0 * bs^2 + pin0) * chunks + chunk0 */
     uint32_t chunk0, pin0, tile0, chunksShift /* log2(chunks) or 32 */, pixShift /* log2(bs^2) or 32 */;
     uint32_t nB, nL, hideEmitters;
+    float diffScale;                 /* 1 / sqrt(spp): RayDifferential::scaleDifferential of the camera ray (integrator.cpp:144-145, 181) */
     uint32_t integrator, strictNormals;   /* KKD_INTEGRATOR_*; 'strictNormals' of the stock direct / path plugins */
     int32_t maxDepth, rrDepth;            /* path plugin: 'maxDepth', 'rrDepth' */
     uint32_t depth;                       /* path plugin: depth of the vertex a kPathBounce launch shades (2, 3, ...) */

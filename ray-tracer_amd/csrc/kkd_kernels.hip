@@ -275,6 +275,24 @@ __global__ void __launch_bounds__(BLOCK, 8) kTraceRound(const Node4 *__restrict_
     }
 }
 
+/* ---- camera rays that leave the scene: filtered environment lookup (kk/direct.cpp:55-57 -> envmap.cpp:379-409) -------------
+ * Runs after kShade (which has stored alpha and zero radiance for these samples) when the scene has an environment emitter
+ * and emitters are not hidden. */
+__global__ void __launch_bounds__(256) kEnvMiss(DScene sc, BatchParams bp, WaveBuffers wb) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= bp.count) return;
+    if (wb.hits[i].id != kNoHit) return;
+    const SampleId s = mapWorkItem(bp, i);
+    if (!s.active) return;
+    float sx, sy;
+    const DRay ray = primaryRay(sc, bp, s, sx, sy);
+    const f3 d(ray.dx, ray.dy, ray.dz); f3 rxD, ryD;
+    sensorDifferentials(sc.sensor, sx, sy, bp.diffScale, d, rxD, ryD);
+    const f3 e = envEvalFiltered(sc.env, d, rxD, ryD);
+    float4 a = wb.accum[i]; a.x = e.x; a.y = e.y; a.z = e.z;
+    wb.accum[i] = a;
+}
+
 /* ---- K4: shade ------------------------------------------------------------------------------------ */
 __device__ __forceinline__ void killRay(DRay &r) { r.ox = r.oy = r.oz = 0.f; r.dx = r.dy = 0.f; r.dz = 1.f; r.mint = 0.f; r.maxt = -1.f; }
 __device__ __forceinline__ void storeRay(DRay *dst, const DRay &r) {
@@ -303,7 +321,7 @@ __global__ void __launch_bounds__(KKD_SHADE_BLOCK, KKD_SHADE_WAVES * 256 / KKD_S
         ray = primaryRay(sc, bp, s, sx, sy);
         if (hit.id == kNoHit) {                                    /* kk/direct.cpp:55-60 */
             if (sc.sensor.filmHasAlpha) accum.w = 0.f;
-            if (!bp.hideEmitters && sc.envEmitter >= 0) { const f3 e = envEval(sc.env, f3(ray.dx, ray.dy, ray.dz)); accum.x = e.x; accum.y = e.y; accum.z = e.z; }
+            /* (the environment seen by a camera ray that leaves the scene is added by kEnvMiss, which runs after this kernel) */
         } else shade = true;
     }
     if (!shade) {
@@ -864,6 +882,7 @@ void launchTracePhased(hipStream_t st, const DScene &sc, const DRay *rays, uint6
 
 void launchShade(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb) {
     hipLaunchKernelGGL(kShade, dim3(blocksFor(bp.count, KKD_SHADE_BLOCK)), dim3(KKD_SHADE_BLOCK), 0, st, sc, bp, wb);
+    if (!bp.hideEmitters && sc.envEmitter >= 0) hipLaunchKernelGGL(kEnvMiss, dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, wb);
 }
 
 void launchPathBounce(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &in, const WaveBuffers &out, const PathLaunch &pl) {

@@ -157,6 +157,115 @@ __device__ __forceinline__ f3 envEval(const DEnvMap &e, f3 worldDir) {
     envBilinearRows(e, uu * e.w - 0.5f, vv * e.h - 0.5f, a, b, yPos);
     return (a + b) * e.scale;
 }
+/* ---- filtered lookup for rays with differentials (camera rays): envmap.cpp:394-407 -> TMIPMap::eval, EWA filter, maxAnisotropy 10.
+ * mipmap.h is not in the checkout: restated from the published Mitsuba 0.5 header (the oracle holds the same restatement),
+ * parity unpinned.  Runs in a kernel of its own (kEnvMiss): inside kShade it cost that kernel 35 spilled registers.  Everything
+ * is inlined: one out-of-line call gave the kernel an 800-byte private segment, and a dispatch whose scratch demand exceeds the
+ * queue's standing allocation has it allocated and freed around every launch (2.3 ms per launch on C4). */
+__device__ __forceinline__ f3 envTexelL(const DEnvMap &e, int level, int x, int y) {
+    const int lw = e.levelW[level], lh = e.levelH[level];
+    x = x % lw; if (x < 0) x += lw;
+    y = min(max(y, 0), lh - 1);
+    const uint2 raw = reinterpret_cast<const uint2 *>(e.texels)[(size_t)e.levelOfs[level] + (size_t)y * lw + x];
+    const __half2 rg = *reinterpret_cast<const __half2 *>(&raw.x), ba = *reinterpret_cast<const __half2 *>(&raw.y);
+    const float2 frg = __half22float2(rg), fba = __half22float2(ba);
+    return f3(frg.x, frg.y, fba.x);
+}
+__device__ __forceinline__ f3 envBilinearL(const DEnvMap &e, int level, float uvx, float uvy) {
+    if (!isfinite(uvx) || !isfinite(uvy)) return f3(0.f);
+    if (level >= e.nLevels) {                          /* evalBox on the coarsest level */
+        const int l = e.nLevels - 1;
+        return envTexelL(e, l, (int)floorf(uvx * (float)e.levelW[l]), (int)floorf(uvy * (float)e.levelH[l]));
+    }
+    const float u = uvx * (float)e.levelW[level] - 0.5f, v = uvy * (float)e.levelH[level] - 0.5f;
+    const int xPos = (int)floorf(u), yPos = (int)floorf(v);
+    const float dx1 = u - xPos, dx2 = 1.0f - dx1, dy1 = v - yPos, dy2 = 1.0f - dy1;
+    return envTexelL(e, level, xPos, yPos) * dx2 * dy2 + envTexelL(e, level, xPos, yPos + 1) * dx2 * dy1
+         + envTexelL(e, level, xPos + 1, yPos) * dx1 * dy2 + envTexelL(e, level, xPos + 1, yPos + 1) * dx1 * dy1;
+}
+__device__ __forceinline__ f3 envEwaL(const DEnvMap &e, int level, float uvx, float uvy, float A, float B, float C) {
+#pragma clang fp contract(off)
+    if (!isfinite(A + B + C + uvx + uvy)) return f3(0.f);
+    if (level >= e.nLevels) return envBilinearL(e, level, uvx, uvy);
+    const float lw = (float)e.levelW[level], lh = (float)e.levelH[level];
+    const float u = uvx * lw - 0.5f, v = uvy * lh - 0.5f;
+    const float ratio0 = fdiv(lw, (float)e.w), ratio1 = fdiv(lh, (float)e.h);
+    A = fdiv(A, ratio0 * ratio0); B = fdiv(B, ratio0 * ratio1); C = fdiv(C, ratio1 * ratio1);
+    const float invDet = fdiv(1.0f, -B * B + 4.0f * A * C), deltaU = 2.0f * sqrtf(C * invDet), deltaV = 2.0f * sqrtf(A * invDet);
+    const int u0 = (int)ceilf(u - deltaU), u1 = (int)floorf(u + deltaU), v0 = (int)ceilf(v - deltaV), v1 = (int)floorf(v + deltaV);
+    const float As = A * 64.f, Bs = B * 64.f, Cs = C * 64.f;
+    f3 result(0.f); float denominator = 0.0f;
+    const float ddq = 2 * As, uu0 = (float)u0 - u;
+    /* the footprint is bounded: minor radius in [1, 2) texels of this level (or the next finer one), major at most 10 x that */
+    for (int vt = v0; vt <= v1; ++vt) {
+        const float vv = (float)vt - v;
+        float q = As * uu0 * uu0 + (Bs * uu0 + Cs * vv) * vv;
+        float dq = As * (2 * uu0 + 1) + Bs * vv;
+        for (int ut = u0; ut <= u1; ++ut) {
+            if (q < 64.f) {
+                const uint32_t qi = (uint32_t)q;
+                if (qi < 64u) {
+                    const float weight = e.ewaLut[(int)q];
+                    result = result + envTexelL(e, level, ut, vt) * weight;
+                    denominator += weight;
+                }
+            }
+            q += dq; dq += ddq;
+        }
+    }
+    if (denominator == 0.f) return envBilinearL(e, level, uvx, uvy);
+    return result / denominator;
+}
+__device__ __forceinline__ f3 envEvalFiltered(const DEnvMap &e, f3 worldDir, f3 rxDir, f3 ryDir) {
+#pragma clang fp contract(off)
+    const f3 v = rot3(e.toLocal, worldDir);
+    const float uvx = atan2f(v.x, -v.z) * kInvTwoPi, uvy = safeAcos(v.y) * kInvPi;
+    const f3 dvdx = rot3(e.toLocal, rxDir) - v, dvdy = rot3(e.toLocal, ryDir) - v;
+    const float t1 = fdiv(kInvTwoPi, v.x * v.x + v.z * v.z), t2 = fdiv(-kInvPi, fmaxf(safeSqrt(1.0f - v.y * v.y), kEpsilon));
+    const float d0x = t1 * (dvdx.z * v.x - dvdx.x * v.z), d0y = t2 * dvdx.y, d1x = t1 * (dvdy.z * v.x - dvdy.x * v.z), d1y = t2 * dvdy.y;
+    const float maxAnisotropy = 10.0f;
+    const float du0 = d0x * (float)e.w, dv0 = d0y * (float)e.h, du1 = d1x * (float)e.w, dv1 = d1y * (float)e.h;
+    float A = dv0 * dv0 + dv1 * dv1, B = -2.0f * (du0 * dv0 + du1 * dv1), C = du0 * du0 + du1 * du1, F = A * C - B * B * 0.25f;
+    const float root = hypotf(A - C, B), Aprime = 0.5f * (A + C - root), Cprime = 0.5f * (A + C + root);
+    float majorRadius = Aprime != 0.f ? sqrtf(fdiv(F, Aprime)) : 0.f, minorRadius = Cprime != 0.f ? sqrtf(fdiv(F, Cprime)) : 0.f;
+    f3 value;
+    if (!(minorRadius > 0.f) || !(majorRadius > 0.f) || F < 0.f) {
+        const float level = log2f(fmaxf(majorRadius, kEpsilon));
+        const int ilevel = (int)floorf(level);
+        if (ilevel < 0) value = envBilinearL(e, 0, uvx, uvy);
+        else { const float a = level - ilevel; value = envBilinearL(e, ilevel, uvx, uvy) * (1.0f - a) + envBilinearL(e, ilevel + 1, uvx, uvy) * a; }
+    } else {
+        if (minorRadius * maxAnisotropy < majorRadius) {
+            minorRadius = fdiv(majorRadius, maxAnisotropy);
+            const float theta = 0.5f * atanf(fdiv(B, A - C));
+            float sinTheta, cosTheta; sincosf(theta, &sinTheta, &cosTheta);
+            const float a2 = majorRadius * majorRadius, b2 = minorRadius * minorRadius, sinTheta2 = sinTheta * sinTheta, cosTheta2 = cosTheta * cosTheta,
+                        sin2Theta = 2 * sinTheta * cosTheta;
+            A = a2 * cosTheta2 + b2 * sinTheta2; B = (a2 - b2) * sin2Theta; C = a2 * sinTheta2 + b2 * cosTheta2; F = a2 * b2;
+        }
+        const float sc = fdiv(1.0f, F);
+        A *= sc; B *= sc; C *= sc;
+        const float level = fmaxf(0.0f, log2f(minorRadius));
+        const int ilevel = (int)level;
+        const float a = level - ilevel;
+        if (majorRadius < 1.f || !(A > 0.f && C > 0.f)) value = envBilinearL(e, ilevel, uvx, uvy);
+        else value = envEwaL(e, ilevel, uvx, uvy, A, B, C) * (1.0f - a) + envEwaL(e, ilevel + 1, uvx, uvy, A, B, C) * a;
+    }
+    return value * e.scale;
+}
+/* perspective.cpp:294-295 + RayDifferential::scaleDifferential (integrator.cpp:181): directions of the rays through the
+ * neighbouring pixels, pulled towards the ray by 1 / sqrt(spp) */
+__device__ __forceinline__ void sensorDifferentials(const DSensor &s, float px, float py, float scale, f3 d, f3 &rxD, f3 &ryD) {
+    const float x = px * s.invResX, y = py * s.invResY;
+    const float *m = s.s2c;
+    float cx = m[0] * x + m[1] * y + m[3], cy = m[4] * x + m[5] * y + m[7], cz = m[8] * x + m[9] * y + m[11], cw = m[12] * x + m[13] * y + m[15];
+    const f3 nearP = (cw == 1.0f) ? f3(cx, cy, cz) : f3(cx, cy, cz) / cw;
+    const f3 dx = normalize(nearP + f3(s.dxCam[0], s.dxCam[1], s.dxCam[2])), dy = normalize(nearP + f3(s.dyCam[0], s.dyCam[1], s.dyCam[2]));
+    const float *w = s.toWorld;
+    rxD = f3(w[0] * dx.x + w[1] * dx.y + w[2] * dx.z, w[4] * dx.x + w[5] * dx.y + w[6] * dx.z, w[8] * dx.x + w[9] * dx.y + w[10] * dx.z);
+    ryD = f3(w[0] * dy.x + w[1] * dy.y + w[2] * dy.z, w[4] * dy.x + w[5] * dy.y + w[6] * dy.z, w[8] * dy.x + w[9] * dy.y + w[10] * dy.z);
+    rxD = d + (rxD - d) * scale; ryD = d + (ryD - d) * scale;
+}
 /* envmap.cpp:603-633 */
 __device__ __forceinline__ float envPdfDirection(const DEnvMap &e, f3 d) {
     const float uu = atan2f(d.x, -d.z) * kInvTwoPi, vv = safeAcos(d.y) * kInvPi;

@@ -95,6 +95,7 @@ struct DEmitter {           /* 64 bytes */
     uint32_t pad;
 };
 
+static constexpr int kEnvMaxLevels = 17;     /* 65535 pixels per side at most (envmap.cpp:161-163) */
 struct DEnvMap {
     int32_t w, h; float scale, normalization;
     float toWorld[9], toLocal[9];
@@ -108,6 +109,10 @@ struct DEnvMap {
      * in [guide[b], guide[b + 1]] and the binary search starts on that bracket (same result, 3-6 dependent loads, not 11-12) */
     const uint32_t *guideRows; /* kEnvGuideRows + 1                                          */
     const uint32_t *guideCols; /* h * (kEnvGuideCols + 1)                                    */
+    /* MIP pyramid of the filtered lookup for camera rays (envmap.cpp:394-407): level l starts at texel levelOfs[l] of
+     * texels and is max(1, ceil(w / 2^l)) x max(1, ceil(h / 2^l)) texels; levelOfs[0] = 0 */
+    int32_t nLevels; uint32_t levelOfs[kEnvMaxLevels]; uint16_t levelW[kEnvMaxLevels], levelH[kEnvMaxLevels];
+    const float *ewaLut;       /* 64 Gaussian weights of the EWA filter (mipmap.h weight table) */
 };
 static constexpr uint32_t kEmitterGuide = 1024, kAreaGuide = 256, kAreaGuideMinPrims = 64;
 static constexpr uint32_t kEnvGuideRows = 256, kEnvGuideCols = 64;   /* powers of two: sample * G is exact */
@@ -117,6 +122,7 @@ struct DSensor {
     float s2c[16];             /* sampleToCamera, full projective 4x4                         */
     float nearClip, farClip, invResX, invResY;
     int32_t cropW, cropH, filmHasAlpha, hqEdges;
+    float dxCam[3], dyCam[3];  /* m_dx, m_dy: near-plane offsets of the neighbouring pixels (perspective.cpp:159-163) */
 };
 
 struct DFilter { float values[32]; float radius, scaleFactor; int32_t border, pad; };
