@@ -209,7 +209,20 @@ typedef struct kkd_render_params {
     int32_t  strict_normals;   /* 'strictNormals' of the direct / path plugins (direct.cpp:103); ignored by KKD_INTEGRATOR_KK */
     int32_t  max_depth;        /* path: 'maxDepth' (-1 = unbounded, 1 = emitted radiance only, 2 = direct illumination ...); 0 is invalid */
     int32_t  rr_depth;         /* path: 'rrDepth', first depth at which Russian roulette is played (> 0; Mitsuba's default 5) */
+    /* which Sampler: KKD_SAMPLER_INDEPENDENT = samplers/independent.cpp:82-103 (every dimension a fresh uniform number);
+     * KKD_SAMPLER_LDSAMPLER = samplers/ldsampler.cpp:148-229, Mitsuba's default: per pixel, each of the first
+     * sampler_dimension 1D / 2D requests and every requested sample array (kk/direct.cpp:44-47: bsdfSamples / lightSamples > 1)
+     * is one (0,2)-sequence over the pixel's samples, randomly scrambled and shuffled; later requests are independent. */
+    uint32_t sampler;
+    uint32_t sampler_dimension;   /* ldsampler 'dimension' (0 = its default 4) */
+    /* Sampler::getSampleCount() of the whole render when this call renders only the share [sample_first, sample_first + spp) of
+     * every pixel's samples (sample-split mode); 0 = spp.  Sets the size of the ldsampler's point sets (rounded up to a power of
+     * two, ldsampler.cpp:83-87) and the scale of the ray differentials (integrator.cpp:144-145). */
+    uint32_t sample_count_total;
+    uint32_t reserved;
 } kkd_render_params;
+#define KKD_SAMPLER_INDEPENDENT 0u
+#define KKD_SAMPLER_LDSAMPLER   1u
 #define KKD_INTEGRATOR_KK     0u
 #define KKD_INTEGRATOR_DIRECT 1u
 #define KKD_INTEGRATOR_PATH   2u
@@ -324,6 +337,11 @@ int kkd_probe_rough_transmittance(int distribution, float alpha, float eta, floa
 /* Discretised reconstruction filter: 32 table values, scale factor and border size as computed by
  * ReconstructionFilter::configure (src/libcore/rfilter.cpp:37-55) for the filters of src/rfilters/. */
 int kkd_probe_rfilter(int rfilter_type, float radius, const float *param2, float *values32, float *scale_factor, int *border);
+
+/* ldsampler point sets (src/samplers/ldsampler.cpp:148-183): the values the device hands to samples 0 ... count-1 of `pixel`
+ * for one stream -- kind 0: 2D request `index` (out: count x 2), kind 1: 1D request `index` (out: count), kind 2: requested
+ * array `index` with `array_n` entries per sample (out: count x array_n x 2) -- when the point sets hold set_size samples. */
+int kkd_probe_ldsampler(uint64_t seed, uint32_t pixel, int kind, uint32_t index, uint32_t array_n, uint32_t set_size, uint32_t count, float *out);
 
 /* ---- film develop and output: the step right after the path ---- */
 

@@ -57,7 +57,7 @@ int ora_render(ora_ctx *c, const kkd_render_params *p, uint64_t seed, int thread
     if (p->integrator == KKD_INTEGRATOR_PATH) { if (!p->spp || p->max_depth == 0 || p->rr_depth <= 0) return KKD_ERR_INVALID; }
     else if (!p->spp || p->bsdf_samples + p->light_samples == 0) return KKD_ERR_UNSUPPORTED;
     if (p->integrator == KKD_INTEGRATOR_KK && (!p->bsdf_samples || !p->light_samples)) return KKD_ERR_UNSUPPORTED;
-    RenderParams rp{ p->spp, p->bsdf_samples, p->light_samples, p->hide_emitters != 0, p->block_size, p->tile_index, p->tile_count, p->sample_first, seed, p->integrator, p->strict_normals != 0, p->max_depth, p->rr_depth };
+    RenderParams rp{ p->spp, p->bsdf_samples, p->light_samples, p->hide_emitters != 0, p->block_size, p->tile_index, p->tile_count, p->sample_first, seed, p->integrator, p->strict_normals != 0, p->max_depth, p->rr_depth, p->sampler, p->sampler_dimension, p->sample_count_total };
     Stats st;
     auto t0 = std::chrono::steady_clock::now();
     c->scene.render(rp, film, &st, threads);
@@ -72,15 +72,16 @@ int ora_render(ora_ctx *c, const kkd_render_params *p, uint64_t seed, int thread
 
 /* Radiance of single camera samples, no film: pix = n x (x, y, sampleIndex); out = n x (r,g,b,alpha,sx,sy). */
 int ora_li_samples(ora_ctx *c, const kkd_render_params *p, uint64_t seed, const uint32_t *pix, uint64_t n, float *out) {
-    RenderParams rp{ p->spp, p->bsdf_samples, p->light_samples, p->hide_emitters != 0, p->block_size, 0, 1, 0, seed, p->integrator, p->strict_normals != 0, p->max_depth, p->rr_depth };
+    RenderParams rp{ p->spp, p->bsdf_samples, p->light_samples, p->hide_emitters != 0, p->block_size, 0, 1, 0, seed, p->integrator, p->strict_normals != 0, p->max_depth, p->rr_depth, p->sampler, p->sampler_dimension, p->sample_count_total };
     const int W = c->scene.sensor.cropW;
     for (uint64_t i = 0; i < n; ++i) {
         uint32_t X = pix[3 * i], Y = pix[3 * i + 1], s = pix[3 * i + 2];
         const int edge = c->scene.hqEdges ? c->scene.filter.borderSize : 0;   /* same pixel key as Scene::render */
         SampleStream rng(seed, (uint32_t)(((int)Y + edge) * (W + 2 * edge) + ((int)X + edge)), s);
+        rp.configure(rng);
         V2 jit = rng.next2D();
         V2 sp{ (Float)X + jit.x, (Float)Y + jit.y };
-        Ray ray = c->scene.sensor.sampleRay(sp, 1.0f / std::sqrt((Float)rp.spp));
+        Ray ray = c->scene.sensor.sampleRay(sp, 1.0f / std::sqrt((Float)rp.total()));
         Float alpha = 1.0f;
         V3 L = c->scene.Li(ray, rng, rp, alpha, nullptr);
         float *o = out + 6 * i; o[0] = L.x; o[1] = L.y; o[2] = L.z; o[3] = alpha; o[4] = sp.x; o[5] = sp.y;
@@ -107,6 +108,16 @@ void ora_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
 void ora_sample_stream(uint64_t seed, uint32_t pixel, uint32_t sample, int n, float *out) {
     SampleStream s(seed, pixel, sample);
     for (int i = 0; i < n; ++i) out[i] = s.next1D();
+}
+/* ldsampler values of samples 0 ... count-1 of one pixel: kind 0 = 2D request `index`, 1 = 1D request `index`, 2 = array `index` */
+void ora_ldsampler(uint64_t seed, uint32_t pixel, int kind, uint32_t index, uint32_t arrayN, uint32_t setSize, uint32_t count, float *out) {
+    for (uint32_t j = 0; j < count; ++j) {
+        SampleStream s(seed, pixel, j);
+        s.useLdSampler(setSize, 0xFFFFFFFFu);
+        if (kind == 0) { s.dim2D = index; V2 v = s.next2D(); out[2 * j] = v.x; out[2 * j + 1] = v.y; }
+        else if (kind == 1) { s.dim1D = index; out[j] = s.next1D(); }
+        else for (uint32_t e = 0; e < arrayN; ++e) { V2 v = s.next2DArray(index, arrayN, e); out[2 * ((size_t)j * arrayN + e)] = v.x; out[2 * ((size_t)j * arrayN + e) + 1] = v.y; }
+    }
 }
 void ora_clip_aabb(const float *tri9, const float *box6, float *out6) {
     AABB b(V3(box6[0], box6[1], box6[2]), V3(box6[3], box6[4], box6[5]));

@@ -40,6 +40,8 @@ def lib():
         L.ora_camera_rays.argtypes = [C.c_void_p, abi.pf32, C.c_uint64, abi.pf32]
         L.ora_philox.argtypes = [abi.pu32, abi.pu32, abi.pu32]
         L.ora_sample_stream.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, abi.pf32]
+        L.ora_ldsampler.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, abi.pf32]
+        L.ora_ldsampler.restype = None
         L.ora_clip_aabb.argtypes = [abi.pf32, abi.pf32, abi.pf32]
         L.ora_bsdf_eval.argtypes = [C.c_void_p, C.c_int, abi.pf32, abi.pf32, abi.pf32, abi.pf32]
         L.ora_bsdf_sample.argtypes = [C.c_void_p, C.c_int, abi.pf32, abi.pf32, C.c_uint64, abi.pf32]
@@ -110,9 +112,10 @@ class Oracle:
         return rays
 
     def render(self, spp, bsdf_samples=1, light_samples=1, hide_emitters=False, seed=1, threads=None, block_size=0,
-               tile_index=0, tile_count=1, sample_first=0, integrator=0, strict_normals=False, max_depth=-1, rr_depth=5):
+               tile_index=0, tile_count=1, sample_first=0, integrator=0, strict_normals=False, max_depth=-1, rr_depth=5,
+               sampler=0, sampler_dimension=0, sample_count_total=0):
         p = abi.RenderParams(spp, bsdf_samples, light_samples, int(hide_emitters), block_size, tile_index, tile_count, sample_first,
-                             integrator, int(strict_normals), max_depth, rr_depth)
+                             integrator, int(strict_normals), max_depth, rr_depth, sampler, sampler_dimension, sample_count_total, 0)
         film = np.zeros((self.height, self.width, 5), np.float32)
         st = abi.Stats()
         rc = lib().ora_render(self.h, C.byref(p), seed, threads or os.cpu_count() or 1, _fp(film), C.byref(st))
@@ -173,6 +176,13 @@ def sample_stream(seed, pixel, sample, n):
     out = np.zeros(n, np.float32)
     lib().ora_sample_stream(seed, pixel, sample, n, _fp(out))
     return out
+
+
+def ldsampler(seed, pixel, kind, index, array_n, set_size, count):
+    """values of samples 0 ... count-1: kind 0 -> (count, 2), 1 -> (count,), 2 -> (count, array_n, 2)"""
+    out = np.zeros(count * (1 if kind == 1 else 2 * (array_n if kind == 2 else 1)), np.float32)
+    lib().ora_ldsampler(seed, pixel, kind, index, array_n, set_size, count, _fp(out))
+    return out if kind == 1 else out.reshape((count, 2) if kind == 0 else (count, array_n, 2))
 
 
 def clip_aabb(tri, box):

@@ -255,13 +255,48 @@ inline Float u32ToFloat(uint32_t u) {
 }
 /* Sample stream of one camera sample: dimension d of (seed, pixel, sample).
  * key = (pixel, seed_lo), counter = (sample, d/4, seed_hi, 0); element d%4. */
+/* qmc.h (absent from the checkout; restated from the published Mitsuba 0.5 header, 24-bit variants; parity unpinned) */
+inline float radicalInverse2Single(uint32_t n, uint32_t scramble = 0U) {
+    n = (n << 16) | (n >> 16);
+    n = ((n & 0x00ff00ff) << 8) | ((n & 0xff00ff00) >> 8);
+    n = ((n & 0x0f0f0f0f) << 4) | ((n & 0xf0f0f0f0) >> 4);
+    n = ((n & 0x33333333) << 2) | ((n & 0xcccccccc) >> 2);
+    n = ((n & 0x55555555) << 1) | ((n & 0xaaaaaaaa) >> 1);
+    n = (n >> (32 - 24)) ^ (scramble & ~-(1 << 24));
+    return (float)n / (float)(1U << 24);
+}
+inline float sobol2Single(uint32_t n, uint32_t scramble = 0U) {
+    for (uint32_t v = 1U << 31; n != 0; n >>= 1, v ^= v >> 1)
+        if (n & 1) scramble ^= v;
+    return (float)(scramble >> 8) / (float)(1U << 24);
+}
+/* the hash permutation that stands in for Random::shuffle (ldsampler.cpp:159, 182): Kensler 2013, a bijection of [0, l) */
+inline uint32_t permuteIndex(uint32_t i, uint32_t l, uint32_t p) {
+    uint32_t w = l - 1;
+    w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
+    do {
+        i ^= p; i *= 0xe170893d; i ^= p >> 16; i ^= (i & w) >> 4; i ^= p >> 8; i *= 0x0929eb3f; i ^= p >> 23; i ^= (i & w) >> 1;
+        i *= 1 | p >> 27; i *= 0x6935fa69; i ^= (i & w) >> 11; i *= 0x74dcb303; i ^= (i & w) >> 2; i *= 0x9e501cc3;
+        i ^= (i & w) >> 2; i *= 0xc860a3df; i &= w; i ^= i >> 5;
+    } while (i >= l);
+    return (i + p) % l;
+}
+
+/* One camera sample's Sampler: independent (samplers/independent.cpp:82-103) or ldsampler (samplers/ldsampler.cpp:148-229).
+ * ldsampler: request k of the sample's 2D (1D) requests, k < ldDim, reads entry `sample` of the pixel's k-th scrambled and
+ * shuffled (0,2)-sequence (van der Corput sequence); next2DArray(a, n, e) reads entry sample * n + e of requested array a; the
+ * scrambles and the shuffle of a (pixel, stream) come from one block of the counter-based generator (the reference draws
+ * them from SFMT, so its values cannot be reproduced either way).  `dim` keeps counting the independent stream's dimensions, so
+ * requests beyond ldDim fall back to the values the independent sampler would have produced there. */
 struct SampleStream {
     uint32_t pixel, sample, seedLo, seedHi;
     uint32_t dim;
     uint32_t cache[4]; int cachedBlock;
+    uint32_t ldSet = 0, ldDim = 0, dim2D = 0, dim1D = 0;       /* ldSet = 0: independent */
     SampleStream(uint64_t seed, uint32_t pix, uint32_t smp)
         : pixel(pix), sample(smp), seedLo((uint32_t)seed), seedHi((uint32_t)(seed >> 32)), dim(0), cachedBlock(-1) {}
-    Float next1D() {
+    void useLdSampler(uint32_t setSize, uint32_t dimension) { ldSet = setSize; ldDim = dimension; }
+    Float independent1D() {
         int block = (int)(dim >> 2);
         if (block != cachedBlock) {
             cache[0] = sample; cache[1] = (uint32_t)block; cache[2] = seedHi; cache[3] = 0;
@@ -270,7 +305,39 @@ struct SampleStream {
         }
         return u32ToFloat(cache[dim++ & 3]);
     }
-    V2 next2D() { Float a = next1D(); Float b = next1D(); return V2{ a, b }; }
+    void streamWords(uint32_t stream, uint32_t r[4]) const {
+        r[0] = stream; r[1] = 0x4C445350u; r[2] = seedHi; r[3] = 1u;
+        Philox::gen(r, pixel, seedLo);
+    }
+    Float next1D() {
+        const uint32_t req = dim1D++;
+        if (ldSet && req < ldDim) {
+            dim += 1;
+            uint32_t r[4]; streamWords(2 * req + 1, r);
+            return radicalInverse2Single(permuteIndex(sample % ldSet, ldSet, r[2]), r[0]);
+        }
+        return independent1D();
+    }
+    V2 next2D() {
+        const uint32_t req = dim2D++;
+        if (ldSet && req < ldDim) {
+            dim += 2;
+            uint32_t r[4]; streamWords(2 * req, r);
+            const uint32_t j = permuteIndex(sample % ldSet, ldSet, r[2]);
+            return V2{ radicalInverse2Single(j, r[0]), sobol2Single(j, r[1]) };
+        }
+        Float a = independent1D(); Float b = independent1D(); return V2{ a, b };
+    }
+    /* element e of this sample's n-element slice of requested array `array` (Sampler::next2DArray, sampler.cpp:79-90) */
+    V2 next2DArray(uint32_t array, uint32_t n, uint32_t e) {
+        if (ldSet) {
+            dim += 2;
+            uint32_t r[4]; streamWords(0x10000u + array, r);
+            const uint32_t size = ldSet * n, j = permuteIndex((sample * n + e) % size, size, r[2]);
+            return V2{ radicalInverse2Single(j, r[0]), sobol2Single(j, r[1]) };
+        }
+        Float a = independent1D(); Float b = independent1D(); return V2{ a, b };
+    }
 };
 
 } /* namespace ora */

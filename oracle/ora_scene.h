@@ -510,7 +510,13 @@ struct Sensor {
 };
 
 struct RenderParams { uint32_t spp, nB, nL; bool hideEmitters; uint32_t blockSize, tileIndex, tileCount, sampleFirst; uint64_t seed;
-                      uint32_t integrator = 0; bool strictNormals = false; int maxDepth = -1, rrDepth = 5; };
+                      uint32_t integrator = 0; bool strictNormals = false; int maxDepth = -1, rrDepth = 5;
+                      uint32_t sampler = 0, samplerDimension = 0, sampleCountTotal = 0;
+                      uint32_t total() const { return sampleCountTotal ? sampleCountTotal : spp; }                /* Sampler::getSampleCount() */
+                      static uint32_t pow2ceil(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
+                      void configure(SampleStream &rng) const {                                                  /* ldsampler.cpp:76-87 */
+                          if (sampler == KKD_SAMPLER_LDSAMPLER) rng.useLdSampler(pow2ceil(total()), samplerDimension ? samplerDimension : 4u);
+                      } };
 struct Stats { std::atomic<uint64_t> samples{0}, raysClosest{0}, raysShadow{0}, nodes{0}, tris{0}; };
 
 class Scene {
@@ -703,7 +709,7 @@ inline V3 Scene::Li(const Ray &ray, SampleStream &rng, const RenderParams &rp, F
     std::vector<SV> brdfSamples, lightSamples;
     /* integrateBrdf :74-125 */
     for (uint32_t i = 0; i < rp.nB; ++i) {
-        V2 u = rng.next2D();
+        V2 u = rp.nB > 1 ? rng.next2DArray(0, rp.nB, i) : rng.next2D();                  /* :80-85; arrays requested at :44-47 */
         V3 woLocal; Float bsdfPdf; uint32_t sampledType;
         V3 bsdfVal = bsdfs.sample(bsdf, its.wi, u, woLocal, bsdfPdf, sampledType);
         if (isZero(bsdfVal)) continue;
@@ -731,7 +737,7 @@ inline V3 Scene::Li(const Ray &ray, SampleStream &rng, const RenderParams &rp, F
     {
         DirectRec dRec; dRec.ref = its.p; dRec.refN = refN;
         for (uint32_t i = 0; i < rp.nL; ++i) {
-            V2 u = rng.next2D();
+            V2 u = rp.nL > 1 ? rng.next2DArray(rp.nB > 1 ? 1 : 0, rp.nL, i) : rng.next2D();
             if (!btype) continue;                          /* :140 (samples are still consumed, :132-137) */
             V3 value = sampleEmitterDirect(dRec, u, st);
             if (isZero(value)) continue;
@@ -769,7 +775,7 @@ inline V3 Scene::LiDirectPlugin(const Ray &ray, const Intersection &its, int bsd
     auto miWeight = [](Float a, Float b) { a *= a; b *= b; return a / (a + b); };        /* :313-316 */
     DirectRec dRec; dRec.ref = its.p; dRec.refN = refN;
     for (uint32_t i = 0; i < rp.nL; ++i) {                                               /* :219-250 */
-        V2 u = rng.next2D();
+        V2 u = rp.nL > 1 ? rng.next2DArray(0, rp.nL, i) : rng.next2D();                  /* :139-143, 210-214 */
         if (!(btype & ESmooth)) continue;
         V3 value = sampleEmitterDirect(dRec, u, st);
         if (isZero(value)) continue;
@@ -783,7 +789,7 @@ inline V3 Scene::LiDirectPlugin(const Ray &ray, const Intersection &its, int bsd
         }
     }
     for (uint32_t i = 0; i < rp.nB; ++i) {                                               /* :256-309 */
-        V2 u = rng.next2D();
+        V2 u = rp.nB > 1 ? rng.next2DArray(rp.nL > 1 ? 1 : 0, rp.nB, i) : rng.next2D();
         V3 woLocal; Float bsdfPdf; uint32_t sampledType;
         V3 bsdfVal = bsdfs.sample(bsdf, its.wi, u, woLocal, bsdfPdf, sampledType);
         if (isZero(bsdfVal)) continue;
@@ -837,7 +843,7 @@ inline V3 Scene::LiPath(const Ray &r, SampleStream &rng, const RenderParams &rp,
         if (shape.emitter >= 0 && emitted && (!rp.hideEmitters || scattered))            /* :148-150 */
             Li += throughput * emitterEvalArea(emitters[shape.emitter], its, -ray.d);
         if ((depth >= rp.maxDepth && rp.maxDepth > 0) || (rp.strictNormals && dot(ray.d, its.geoFrame.n) * its.wi.z >= 0)) break;   /* :156-165 */
-        rng.dim = 2u + 6u * (uint32_t)(depth - 1);
+        rng.dim = 2u + 6u * (uint32_t)(depth - 1); rng.dim2D = 1u + 2u * (uint32_t)(depth - 1);   /* request numbers are fixed per vertex */
         const uint32_t btype = bsdfs.getType(bsdf);
         DirectRec dRec; dRec.ref = its.p; dRec.refN = (btype & (ETransmission | EBackSide)) ? V3(0.f) : its.shFrame.n;
         {                                                                                /* :172-200 */
@@ -928,9 +934,10 @@ inline void Scene::render(const RenderParams &rp, float *film, Stats *st, int nT
                 const int X = ox + px, Y = oy + py;
                 for (uint32_t j = 0; j < rp.spp; ++j) {
                     SampleStream rng(rp.seed, (uint32_t)((Y + edge) * EW + (X + edge)), rp.sampleFirst + j);
+                    rp.configure(rng);
                     V2 jit = rng.next2D();
                     V2 samplePos{ (Float)X + jit.x, (Float)Y + jit.y };
-                    Ray ray = sensor.sampleRay(samplePos, 1.0f / std::sqrt((Float)rp.spp));   /* integrator.cpp:144-145, 181 */
+                    Ray ray = sensor.sampleRay(samplePos, 1.0f / std::sqrt((Float)rp.total()));   /* integrator.cpp:144-145, 181 */
                     Float alpha = 1.0f;
                     V3 spec = Li(ray, rng, rp, alpha, st);
                     if (st) st->samples++;

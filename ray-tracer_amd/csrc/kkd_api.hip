@@ -151,6 +151,19 @@ int kkd_probe_rough_transmittance(int distribution, float alpha, float eta, floa
     return KKD_OK;
 }
 
+int kkd_probe_ldsampler(uint64_t seed, uint32_t pixel, int kind, uint32_t index, uint32_t array_n, uint32_t set_size, uint32_t count, float *out) {
+    if (!out || !set_size || (set_size & (set_size - 1u)) || kind < 0 || kind > 2 || (kind == 2 && !array_n)) return KKD_ERR_INVALID;
+    for (uint32_t j = 0; j < count; ++j) {
+        if (kind == 0) { const f2 v = ldSample2D(seed, pixel, 2u * index, j, set_size); out[2 * j] = v.x; out[2 * j + 1] = v.y; }
+        else if (kind == 1) out[j] = ldSample1D(seed, pixel, 2u * index + 1u, j, set_size);
+        else for (uint32_t e = 0; e < array_n; ++e) {
+            const f2 v = ldSample2D(seed, pixel, 0x10000u + index, j * array_n + e, set_size * array_n);
+            out[2 * ((size_t)j * array_n + e)] = v.x; out[2 * ((size_t)j * array_n + e) + 1] = v.y;
+        }
+    }
+    return KKD_OK;
+}
+
 int kkd_probe_rfilter(int rfilter_type, float radius, const float *param2, float *values32, float *scale_factor, int *border) {
     if (!param2 || !values32 || !scale_factor || !border || rfilter_type < 0 || rfilter_type > KKD_RFILTER_LANCZOS || !(radius > 0.f)) return KKD_ERR_INVALID;
     DFilter f;
@@ -472,6 +485,11 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     if (rp->spp == 0) return fail(ctx, KKD_ERR_INVALID, "spp must be positive");
     /* kk/direct.cpp:165-166 divides by both counts: zero is not a meaningful configuration */
     if (rp->integrator > KKD_INTEGRATOR_PATH) return fail(ctx, KKD_ERR_INVALID, "unknown integrator");
+    if (rp->sampler > KKD_SAMPLER_LDSAMPLER) return fail(ctx, KKD_ERR_INVALID, "unknown sampler");
+    if (rp->sample_count_total && (uint64_t)rp->sample_first + rp->spp > rp->sample_count_total)
+        return fail(ctx, KKD_ERR_INVALID, "sample_first + spp exceeds sample_count_total");
+    if (rp->sampler == KKD_SAMPLER_LDSAMPLER && (uint64_t)(rp->sample_count_total ? rp->sample_count_total : rp->spp) * 64u > 0x40000000ull)
+        return fail(ctx, KKD_ERR_UNSUPPORTED, "ldsampler: more than 2^24 samples per pixel");
     const bool pathMode = rp->integrator == KKD_INTEGRATOR_PATH;
     /* MonteCarloIntegrator (librender/integrator.cpp:190-233): maxDepth = -1 or > 0, rrDepth > 0 */
     if (pathMode && (rp->max_depth == 0 || rp->max_depth < -1)) return fail(ctx, KKD_ERR_INVALID, "maxDepth must be -1 (unbounded) or positive");
@@ -585,7 +603,11 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     bp.seed = ctx->cfg.seed; bp.stride = (uint32_t)S;
     bp.g = g; bp.gShift = gShift; bp.chunks = chunks; bp.spp = rp->spp; bp.sampleFirst = rp->sample_first;
     bp.nB = nB; bp.nL = nL; bp.hideEmitters = rp->hide_emitters != 0;
-    bp.diffScale = 1.0f / std::sqrt((float)rp->spp);
+    /* Sampler::getSampleCount(): of the whole render when this call renders a share of every pixel's samples */
+    const uint32_t sampleCountTotal = rp->sample_count_total ? rp->sample_count_total : rp->spp;
+    bp.diffScale = 1.0f / std::sqrt((float)sampleCountTotal);
+    bp.sampler = rp->sampler; bp.samplerDim = rp->sampler_dimension ? rp->sampler_dimension : 4u;   /* ldsampler.cpp:81 */
+    bp.samplerSet = pow2ceil(sampleCountTotal);                                                      /* ldsampler.cpp:83-87 */
     bp.integrator = rp->integrator; bp.strictNormals = rp->strict_normals != 0;
     bp.maxDepth = rp->max_depth; bp.rrDepth = rp->rr_depth; bp.depth = 1;
     bp.chunksShift = 32; bp.pixShift = 32;
@@ -948,7 +970,8 @@ static int multiRender(kkd_multi *m, const kkd_render_params *rp, float *rootDev
     uint32_t sampleAt = rp->sample_first;
     for (uint32_t r = 0; r < n; ++r) {
         if (m->split == KKD_SPLIT_TILE) { prm[r].tile_count = outerCount * n; prm[r].tile_index = outerIndex * n + r; }
-        else { prm[r].spp = rp->spp / n + (r < rp->spp % n ? 1u : 0u); prm[r].sample_first = sampleAt; sampleAt += prm[r].spp; }
+        else { prm[r].spp = rp->spp / n + (r < rp->spp % n ? 1u : 0u); prm[r].sample_first = sampleAt; sampleAt += prm[r].spp;
+               if (!prm[r].sample_count_total) prm[r].sample_count_total = rp->sample_first + rp->spp; }
     }
     std::vector<kkd_stats> st(n);
     std::vector<int> rcs(n, KKD_OK);

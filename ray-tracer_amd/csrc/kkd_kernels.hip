@@ -66,8 +66,25 @@ __device__ __forceinline__ SampleId mapWorkItem(const BatchParams &bp, uint32_t 
     return s;
 }
 
-__device__ __forceinline__ DRay primaryRay(const DScene &sc, const BatchParams &bp, const SampleId &s, float &sx, float &sy) {
-    const f2 jit = sample2D(bp.seed, s.pixel, s.sample, 0);
+/* Sampler::next2D / next2DArray / next1D of sample s: `flat` is the dimension of the independent stream (what every request
+ * beyond the ldsampler's 'dimension' falls back to, ldsampler.cpp:214-228), `req` the running number of the 2D (1D) request
+ * within the sample, (array, n, e) element e of the sample's n-element slice of requested array `array`.  ld: the ldsampler is
+ * in use -- a compile-time constant in kShade, whose register budget has no room for both samplers. */
+__device__ __forceinline__ f2 draw2D(const BatchParams &bp, const SampleId &s, uint32_t flat, uint32_t req, bool ld) {
+    if (ld && req < bp.samplerDim) return ldSample2D(bp.seed, s.pixel, 2u * req, s.sample, bp.samplerSet);
+    return sample2D(bp.seed, s.pixel, s.sample, flat);
+}
+__device__ __forceinline__ f2 draw2DArray(const BatchParams &bp, const SampleId &s, uint32_t flat, uint32_t array, uint32_t n, uint32_t e, bool ld) {
+    if (ld) return ldSample2D(bp.seed, s.pixel, 0x10000u + array, s.sample * n + e, bp.samplerSet * n);
+    return sample2D(bp.seed, s.pixel, s.sample, flat);
+}
+__device__ __forceinline__ float draw1D(const BatchParams &bp, const SampleId &s, uint32_t flat, uint32_t req, bool ld) {
+    if (ld && req < bp.samplerDim) return ldSample1D(bp.seed, s.pixel, 2u * req + 1u, s.sample, bp.samplerSet);
+    return sample2D(bp.seed, s.pixel, s.sample, flat).x;
+}
+
+__device__ __forceinline__ DRay primaryRay(const DScene &sc, const BatchParams &bp, const SampleId &s, float &sx, float &sy, bool ld) {
+    const f2 jit = draw2D(bp, s, 0u, 0u, ld);
     sx = (float)s.X + jit.x; sy = (float)s.Y + jit.y;      /* integrator.cpp:171 */
     return sensorRay(sc.sensor, sx, sy);
 }
@@ -103,7 +120,7 @@ __global__ void __launch_bounds__(BLOCK, !PACKET || KKD_PRIMARY_RAYS == 1 ? 8 : 
         ray[r].maxt = -1.f; ray[r].mint = 0.f; ray[r].ox = ray[r].oy = ray[r].oz = 0.f; ray[r].dx = ray[r].dy = 0.f; ray[r].dz = 1.f;
         float sx, sy;
         active[r] = s.active;
-        if (s.active) ray[r] = primaryRay(sc, bp, s, sx, sy);
+        if (s.active) ray[r] = primaryRay(sc, bp, s, sx, sy, bp.sampler == KKD_SAMPLER_LDSAMPLER);
     }
     const void *triTable = PROJ ? (const void *)sc.projTris : (const void *)sc.tris;
     if (PACKET) traversePacket<COUNT, PROJ, R>(sc.wideNodes, triTable, ray, sstack + (threadIdx.x >> 6) * kMaxTraversalStack, h, nn, nt);
@@ -285,7 +302,7 @@ __global__ void __launch_bounds__(256) kEnvMiss(DScene sc, BatchParams bp, WaveB
     const SampleId s = mapWorkItem(bp, i);
     if (!s.active) return;
     float sx, sy;
-    const DRay ray = primaryRay(sc, bp, s, sx, sy);
+    const DRay ray = primaryRay(sc, bp, s, sx, sy, bp.sampler == KKD_SAMPLER_LDSAMPLER);
     const f3 d(ray.dx, ray.dy, ray.dz); f3 rxD, ryD;
     sensorDifferentials(sc.sensor, sx, sy, bp.diffScale, d, rxD, ryD);
     const f3 e = envEvalFiltered(sc.env, d, rxD, ryD);
@@ -308,6 +325,7 @@ __device__ __forceinline__ void storeRay(DRay *dst, const DRay &r) {
                                   64-spp C4 frame, but kResolve is starved instead, 120 instead of 42 ms: the frame time does not move, 198.0 vs
                                   197.6 ms -- the pipeline as a whole is bound by VALU issue, lanes only redistribute it) */
 #endif
+template <bool LD>      /* the ldsampler is in use */
 __global__ void __launch_bounds__(KKD_SHADE_BLOCK, KKD_SHADE_WAVES * 256 / KKD_SHADE_BLOCK) kShade(DScene sc, BatchParams bp, WaveBuffers wb) {
     const uint32_t i = blockIdx.x * KKD_SHADE_BLOCK + threadIdx.x;
     if (i >= bp.count) return;
@@ -318,7 +336,7 @@ __global__ void __launch_bounds__(KKD_SHADE_BLOCK, KKD_SHADE_WAVES * 256 / KKD_S
     bool shade = false;
     Its its; DRay ray; float sx, sy;
     if (s.active) {
-        ray = primaryRay(sc, bp, s, sx, sy);
+        ray = primaryRay(sc, bp, s, sx, sy, LD);
         if (hit.id == kNoHit) {                                    /* kk/direct.cpp:55-60 */
             if (sc.sensor.filmHasAlpha) accum.w = 0.f;
             /* (the environment seen by a camera ray that leaves the scene is added by kEnvMiss, which runs after this kernel) */
@@ -352,7 +370,11 @@ __global__ void __launch_bounds__(KKD_SHADE_BLOCK, KKD_SHADE_WAVES * 256 / KKD_S
 
     /* integrateBrdf :74-104 -- the part before the ray is traced */
     for (uint32_t b = 0; b < nB; ++b) {
-        const f2 u = sample2D(bp.seed, s.pixel, s.sample, 2u + 2u * b + (stock ? 2u * nL : 0u));
+        /* kk: BSDF samples are requested first (kk/direct.cpp:44-47, 80-85), the stock plugins ask for the emitter samples first
+         * (direct.cpp:139-143, 219); a count of one is a plain next2D, more are a slice of a requested array */
+        const uint32_t flatB = 2u + 2u * b + (stock ? 2u * nL : 0u);
+        const f2 u = nB > 1u ? draw2DArray(bp, s, flatB, (stock && nL > 1u) ? 1u : 0u, nB, b, LD)
+                             : draw2D(bp, s, flatB, 1u + ((stock && nL == 1u) ? 1u : 0u), LD);
         f3 woLocal; float bsdfPdf; uint32_t sampledType;
         const f3 bsdfVal = sampleBsdf(sc, its.material, its.wi, u, woLocal, bsdfPdf, sampledType);
         DRay r; killRay(r);
@@ -376,7 +398,9 @@ __global__ void __launch_bounds__(KKD_SHADE_BLOCK, KKD_SHADE_WAVES * 256 / KKD_S
         DRay r; killRay(r);
         float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
         if ((stock ? (btype & ESmooth) != 0u && !dead : btype != 0u) && sc.nEmitters) {      /* :140; direct.cpp:215 */
-            const f2 u = sample2D(bp.seed, s.pixel, s.sample, 2u + 2u * l + (stock ? 0u : 2u * nB));
+            const uint32_t flatL = 2u + 2u * l + (stock ? 0u : 2u * nB);
+            const f2 u = nL > 1u ? draw2DArray(bp, s, flatL, (!stock && nB > 1u) ? 1u : 0u, nL, l, LD)
+                                 : draw2D(bp, s, flatL, 1u + ((!stock && nB == 1u) ? 1u : 0u), LD);
             DirectRec dRec; dRec.ref = its.p; dRec.refN = refN; dRec.emitter = -1;
             const f3 value = sampleEmitterDirectUnoccluded(sc, dRec, u);
             if (!isZero(value)) {
@@ -467,8 +491,8 @@ __global__ void __launch_bounds__(256, 4) kPathBounce(DScene sc, BatchParams bp,
             if (pl.terminate) cont = false;
             if (cont && (int)bp.depth - 1 >= bp.rrDepth) {                               /* :276-286, depth before the increment */
                 const float q = fminf(maxComp(T) * eta * eta, 0.95f);
-                const f2 u = sample2D(bp.seed, s.pixel, s.sample, 2u + 6u * (bp.depth - 2u) + 4u);
-                if (u.x >= q) cont = false; else T = T / q;
+                const float u = draw1D(bp, s, 2u + 6u * (bp.depth - 2u) + 4u, bp.depth - 1u - (uint32_t)bp.rrDepth, bp.sampler == KKD_SAMPLER_LDSAMPLER);   /* the roulette is the path's only 1D request */
+                if (u >= q) cont = false; else T = T / q;
             }
             if (cont && ((bp.maxDepth > 0 && (int)bp.depth >= bp.maxDepth) || (bp.strictNormals && dot(rd, its.geoN) * its.wi.z >= 0.f))) cont = false;   /* :156-165 */
             if (cont) {
@@ -477,7 +501,7 @@ __global__ void __launch_bounds__(256, 4) kPathBounce(DScene sc, BatchParams bp,
                 const f3 refN = (btype & (ETransmission | EBackSide)) ? f3(0.f) : its.sh.n;
                 nrefN = make_float4(refN.x, refN.y, refN.z, eta);
                 if ((btype & ESmooth) != 0u && sc.nEmitters) {                           /* :172-200 */
-                    const f2 u = sample2D(bp.seed, s.pixel, s.sample, dim0);
+                    const f2 u = draw2D(bp, s, dim0, 1u + 2u * (bp.depth - 1u), bp.sampler == KKD_SAMPLER_LDSAMPLER);
                     DirectRec lRec; lRec.ref = its.p; lRec.refN = refN; lRec.emitter = -1;
                     const f3 lval = sampleEmitterDirectUnoccluded(sc, lRec, u);
                     if (!isZero(lval)) {
@@ -495,7 +519,7 @@ __global__ void __launch_bounds__(256, 4) kPathBounce(DScene sc, BatchParams bp,
                         }
                     }
                 }
-                const f2 u = sample2D(bp.seed, s.pixel, s.sample, dim0 + 2u);             /* :206-225 */
+                const f2 u = draw2D(bp, s, dim0 + 2u, 2u + 2u * (bp.depth - 1u), bp.sampler == KKD_SAMPLER_LDSAMPLER);             /* :206-225 */
                 f3 woLocal; float pdf; uint32_t sampledType;
                 const f3 bsdfWeight = sampleBsdf(sc, its.material, its.wi, u, woLocal, pdf, sampledType);
                 if (!isZero(bsdfWeight)) {
@@ -636,7 +660,7 @@ __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveB
     float val[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
     float sx = 0.f, sy = 0.f;
     if (s.active) {
-        const f2 jit = sample2D(bp.seed, s.pixel, s.sample, 0);
+        const f2 jit = draw2D(bp, s, 0u, 0u, bp.sampler == KKD_SAMPLER_LDSAMPLER);
         sx = (float)s.X + jit.x; sy = (float)s.Y + jit.y;
         const float4 acc = wb.accum[i];
         f3 L(acc.x, acc.y, acc.z);
@@ -881,7 +905,8 @@ void launchTracePhased(hipStream_t st, const DScene &sc, const DRay *rays, uint6
 }
 
 void launchShade(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb) {
-    hipLaunchKernelGGL(kShade, dim3(blocksFor(bp.count, KKD_SHADE_BLOCK)), dim3(KKD_SHADE_BLOCK), 0, st, sc, bp, wb);
+    if (bp.sampler == KKD_SAMPLER_LDSAMPLER) hipLaunchKernelGGL(kShade<true>, dim3(blocksFor(bp.count, KKD_SHADE_BLOCK)), dim3(KKD_SHADE_BLOCK), 0, st, sc, bp, wb);
+    else hipLaunchKernelGGL(kShade<false>, dim3(blocksFor(bp.count, KKD_SHADE_BLOCK)), dim3(KKD_SHADE_BLOCK), 0, st, sc, bp, wb);
     if (!bp.hideEmitters && sc.envEmitter >= 0) hipLaunchKernelGGL(kEnvMiss, dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, wb);
 }
 

@@ -91,9 +91,10 @@ class Context:
 
     @staticmethod
     def _params(spp, bsdf_samples, light_samples, hide_emitters, block_size, tile_index, tile_count, sample_first,
-                integrator=abi.INTEGRATOR_KK, strict_normals=False, max_depth=-1, rr_depth=5):
+                integrator=abi.INTEGRATOR_KK, strict_normals=False, max_depth=-1, rr_depth=5,
+                sampler=abi.SAMPLER_INDEPENDENT, sampler_dimension=0, sample_count_total=0):
         return abi.RenderParams(spp, bsdf_samples, light_samples, int(hide_emitters), block_size, tile_index, tile_count, sample_first,
-                                integrator, int(strict_normals), max_depth, rr_depth)
+                                integrator, int(strict_normals), max_depth, rr_depth, sampler, sampler_dimension, sample_count_total, 0)
 
     def set_progress_callback(self, fn):
         """fn(samples_done, samples_total) is called between batches of a render (kkd_set_progress_callback); None removes it."""
@@ -101,20 +102,22 @@ class Context:
         self._check(self.lib.kkd_set_progress_callback(self.h, self._progress, None))
 
     def render(self, spp, bsdf_samples=1, light_samples=1, hide_emitters=False, block_size=0, tile_index=0, tile_count=1,
-               sample_first=0, integrator=abi.INTEGRATOR_KK, strict_normals=False, max_depth=-1, rr_depth=5):
+               sample_first=0, integrator=abi.INTEGRATOR_KK, strict_normals=False, max_depth=-1, rr_depth=5,
+               sampler=abi.SAMPLER_INDEPENDENT, sampler_dimension=0, sample_count_total=0):
         """-> (film[H, W, 5] float32 = {R*w, G*w, B*w, alpha*w, w}, abi.Stats)"""
         p = self._params(spp, bsdf_samples, light_samples, hide_emitters, block_size, tile_index, tile_count, sample_first,
-                         integrator, strict_normals, max_depth, rr_depth)
+                         integrator, strict_normals, max_depth, rr_depth, sampler, sampler_dimension, sample_count_total)
         film = np.zeros((self.height, self.width, 5), np.float32)
         st = abi.Stats()
         self._check(self.lib.kkd_render(self.h, C.byref(p), film.ctypes.data_as(abi.pf32), C.byref(st)))
         return film, st
 
     def render_device(self, dev_ptr, spp, bsdf_samples=1, light_samples=1, hide_emitters=False, block_size=0, tile_index=0,
-                      tile_count=1, sample_first=0, integrator=abi.INTEGRATOR_KK, strict_normals=False, max_depth=-1, rr_depth=5):
+                      tile_count=1, sample_first=0, integrator=abi.INTEGRATOR_KK, strict_normals=False, max_depth=-1, rr_depth=5,
+                      sampler=abi.SAMPLER_INDEPENDENT, sampler_dimension=0, sample_count_total=0):
         """Render into caller-owned device memory (H*W*5 floats, e.g. tensor.data_ptr()); -> abi.Stats"""
         p = self._params(spp, bsdf_samples, light_samples, hide_emitters, block_size, tile_index, tile_count, sample_first,
-                         integrator, strict_normals, max_depth, rr_depth)
+                         integrator, strict_normals, max_depth, rr_depth, sampler, sampler_dimension, sample_count_total)
         st = abi.Stats()
         self._check(self.lib.kkd_render_device(self.h, C.byref(p), C.c_void_p(dev_ptr), C.byref(st)))
         return st
@@ -212,18 +215,20 @@ class MultiContext:
         return self.lib.kkd_multi_merge_path(self.h).decode()
 
     def render(self, spp, bsdf_samples=1, light_samples=1, hide_emitters=False, block_size=0, tile_index=0, tile_count=1,
-               sample_first=0, integrator=abi.INTEGRATOR_KK, strict_normals=False, max_depth=-1, rr_depth=5):
+               sample_first=0, integrator=abi.INTEGRATOR_KK, strict_normals=False, max_depth=-1, rr_depth=5,
+               sampler=abi.SAMPLER_INDEPENDENT, sampler_dimension=0, sample_count_total=0):
         p = Context._params(spp, bsdf_samples, light_samples, hide_emitters, block_size, tile_index, tile_count, sample_first,
-                            integrator, strict_normals, max_depth, rr_depth)
+                            integrator, strict_normals, max_depth, rr_depth, sampler, sampler_dimension, sample_count_total)
         film = np.zeros((self.height, self.width, 5), np.float32)
         st = abi.Stats()
         self._check(self.lib.kkd_multi_render(self.h, C.byref(p), film.ctypes.data_as(abi.pf32), C.byref(st)))
         return film, st
 
     def render_device(self, dev_ptr, spp, bsdf_samples=1, light_samples=1, hide_emitters=False, block_size=0, tile_index=0,
-                      tile_count=1, sample_first=0, integrator=abi.INTEGRATOR_KK, strict_normals=False, max_depth=-1, rr_depth=5):
+                      tile_count=1, sample_first=0, integrator=abi.INTEGRATOR_KK, strict_normals=False, max_depth=-1, rr_depth=5,
+                      sampler=abi.SAMPLER_INDEPENDENT, sampler_dimension=0, sample_count_total=0):
         p = Context._params(spp, bsdf_samples, light_samples, hide_emitters, block_size, tile_index, tile_count, sample_first,
-                            integrator, strict_normals, max_depth, rr_depth)
+                            integrator, strict_normals, max_depth, rr_depth, sampler, sampler_dimension, sample_count_total)
         st = abi.Stats()
         self._check(self.lib.kkd_multi_render_device(self.h, C.byref(p), C.c_void_p(dev_ptr), C.byref(st)))
         return st
@@ -339,6 +344,44 @@ def save_serialized(path, meshes):
     _io_check(lib.kkd_mesh_save_serialized(os.fsencode(path), arr, len(meshes)), "kkd_mesh_save_serialized")
 
 
+class IndependentSampler:
+    """Host mirror of the 'independent' sampler plugin (reference src/samplers/independent.cpp:30-60): sampleCount."""
+    PLUGIN_NAME = "independent"
+
+    def __init__(self, props=None, **kw):
+        props = dict(props or {}, **kw)
+        self.sampleCount = int(props.pop("sampleCount", 4))
+        if props:
+            raise ValueError("independent: unreferenced properties %s" % sorted(props))
+
+    def render_args(self):
+        return dict(sampler=abi.SAMPLER_INDEPENDENT)
+
+
+class LowDiscrepancySampler:
+    """Host mirror of the 'ldsampler' plugin, Mitsuba's default (reference src/samplers/ldsampler.cpp:76-98): sampleCount is
+    rounded up to a power of two with a warning, 'dimension' low-discrepancy requests per sample (default 4)."""
+    PLUGIN_NAME = "ldsampler"
+
+    def __init__(self, props=None, **kw):
+        props = dict(props or {}, **kw)
+        self.sampleCount = int(props.pop("sampleCount", 4))
+        self.dimension = int(props.pop("dimension", 4))
+        if props:
+            raise ValueError("ldsampler: unreferenced properties %s" % sorted(props))
+        if self.sampleCount < 1 or self.dimension < 0:
+            raise ValueError("ldsampler: sampleCount must be positive, dimension non-negative")
+        if self.sampleCount & (self.sampleCount - 1):
+            import warnings
+            rounded = 1 << self.sampleCount.bit_length()
+            warnings.warn("Sample count should be a power of two -- rounding to %d" % rounded)
+            self.sampleCount = rounded
+
+    def render_args(self):
+        # dimension 0 means "the default" at the C ABI; a sampler without low-discrepancy requests is the independent one
+        return dict(sampler=abi.SAMPLER_LDSAMPLER, sampler_dimension=self.dimension) if self.dimension else dict(sampler=abi.SAMPLER_INDEPENDENT)
+
+
 class DirectIntegrator:
     """Host mirror of the reference's DirectIntegrator plugin (src/integrators/kk/direct.cpp:15-48).
 
@@ -368,14 +411,20 @@ class DirectIntegrator:
         b, l, h = struct.unpack("<QQ?", blob)
         return cls(bsdfSamples=b, lightSamples=l, hideEmitters=h)
 
-    def render(self, scene, spp, device=0, seed=1, block_size=0, tile_index=0, tile_count=1, sample_first=0, ctx=None):
-        """Integrator::render for this path: returns (film, stats); film is what Film::put receives."""
+    def render(self, scene, spp=None, device=0, seed=1, block_size=0, tile_index=0, tile_count=1, sample_first=0, ctx=None, sampler=None):
+        """Integrator::render for this path: returns (film, stats); film is what Film::put receives.  sampler: an
+        IndependentSampler / LowDiscrepancySampler (its sampleCount is the spp, integrator.cpp:103-104) or None."""
         own = ctx is None
         if own:
             ctx = Context(device=device, seed=seed).upload(scene)
         self._cancel_targets.append(ctx)
         try:
-            return ctx.render(spp, self.bsdfSamples, self.lightSamples, self.hideEmitters, block_size, tile_index, tile_count, sample_first)
+            if spp is None:
+                if sampler is None:
+                    raise ValueError("kkIntegrator.render: spp or a sampler is needed")
+                spp = sampler.sampleCount
+            return ctx.render(spp, self.bsdfSamples, self.lightSamples, self.hideEmitters, block_size, tile_index, tile_count, sample_first,
+                              **(sampler.render_args() if sampler is not None else {}))
         finally:
             self._cancel_targets.remove(ctx)
             if own:

@@ -85,10 +85,12 @@ PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64)
 class RenderParams(C.Structure):
     _fields_ = [("spp", u32), ("bsdf_samples", u32), ("light_samples", u32), ("hide_emitters", i32),
                 ("block_size", u32), ("tile_index", u32), ("tile_count", u32), ("sample_first", u32),
-                ("integrator", u32), ("strict_normals", i32), ("max_depth", i32), ("rr_depth", i32)]
+                ("integrator", u32), ("strict_normals", i32), ("max_depth", i32), ("rr_depth", i32),
+                ("sampler", u32), ("sampler_dimension", u32), ("sample_count_total", u32), ("reserved", u32)]
 
 
 INTEGRATOR_KK, INTEGRATOR_DIRECT, INTEGRATOR_PATH = 0, 1, 2
+SAMPLER_INDEPENDENT, SAMPLER_LDSAMPLER = 0, 1
 
 
 class Stats(C.Structure):
@@ -123,6 +125,7 @@ ENTRY_POINTS = {
     "kkd_trace_counted": (C.c_int, [C.c_void_p, pf32, u64, C.c_int, C.POINTER(Hit), C.POINTER(Stats)]),
     "kkd_accel_info": (C.c_int, [C.c_void_p, pu32, pu32, C.POINTER(u64), C.POINTER(u64)]),
     "kkd_probe_rough_transmittance": (C.c_int, [C.c_int, C.c_float, C.c_float, pf32, pf32]),
+    "kkd_probe_ldsampler": (C.c_int, [u64, u32, C.c_int, u32, u32, u32, u32, pf32]),
     "kkd_probe_rfilter": (C.c_int, [C.c_int, C.c_float, pf32, pf32, pf32, C.POINTER(C.c_int)]),
     "kkd_develop_device": (C.c_int, [C.c_void_p, C.c_void_p, u32, u32, i32, C.c_void_p]),
     "kkd_develop": (C.c_int, [C.c_void_p, pf32, u32, u32, i32, pf32]),
