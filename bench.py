@@ -79,8 +79,8 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override the workload's spp (then the line is not the headline config)")
     ap.add_argument("--scale", type=float, default=1.0, help="resolution scale (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--leaf-test", default="watertight", choices=["watertight", "projection"],
-                    help="projection = KKD_FLAG_PROJECTION_TEST (the reference's TriAccel arithmetic, bit-identical hit ids)")
+    ap.add_argument("--leaf-test", default="projection", choices=["watertight", "projection"],
+                    help="projection (the library's default) = the reference's TriAccel arithmetic, bit-identical hit ids; watertight = KKD_FLAG_WATERTIGHT_TEST")
     ap.add_argument("--integrator", default="kk", choices=["kk", "direct", "path"],
                     help="kk = the headline path; direct / path = the sibling plugins on the same kernels (not the headline metric)")
     ap.add_argument("--max-depth", type=int, default=-1, help="path: maxDepth")

@@ -220,12 +220,13 @@ static int uploadHostScene(kkd_ctx *ctx, const HostScene &hs, const kkd_scene_de
     int rc;
 #define UP(buf, ptr, n) if ((rc = upload(ctx, ctx->buf, ptr, n)) != KKD_OK) return rc;
     const bool gpuBuild = (ctx->cfg.flags & KKD_FLAG_GPU_BUILD) != 0;
+    const bool projTest = (ctx->cfg.flags & KKD_FLAG_WATERTIGHT_TEST) == 0;   /* the reference's leaf test unless the caller asks for the watertight one */
     std::vector<ProjTri> pt;   /* read by an asynchronous copy: lives until the stream has been synchronised below */
     if (!gpuBuild) {
         UP(nodes, hs.bvh.nodes.data(), hs.bvh.nodes.size())
         UP(wideNodes, hs.bvh.wide.data(), hs.bvh.wide.size())
         UP(tris, hs.bvh.tris.data(), hs.bvh.tris.size())
-        if (ctx->cfg.flags & KKD_FLAG_PROJECTION_TEST) {
+        if (projTest) {
             makeProjTris(hs.bvh.tris, pt);
             UP(projTris, pt.data(), pt.size())
         }
@@ -265,19 +266,19 @@ static int uploadHostScene(kkd_ctx *ctx, const HostScene &hs, const kkd_scene_de
         if (e != hipSuccess) return fail(ctx, e == hipErrorInvalidValue ? KKD_ERR_INVALID : (e == hipErrorOutOfMemory ? KKD_ERR_NOMEM : KKD_ERR_DEVICE), "device build: " + berr);
         if (res.maxStack > kMaxTraversalStack) return fail(ctx, KKD_ERR_UNSUPPORTED, "acceleration structure deeper than the traversal stack");
         accel = BVH4::Info(); accel.nNodes = res.nNodes; accel.nLeafTris = nTris; accel.maxDepth = res.maxDepth; accel.maxStack = res.maxStack;
-        if (ctx->cfg.flags & KKD_FLAG_PROJECTION_TEST) {
-            /* the TriAccel table follows the leaf order: read the leaf records back and build it as the host path does */
-            std::vector<LeafTri> lt(nTris);
-            KKD_HIP(ctx, hipMemcpy(lt.data(), ctx->tris.p, (size_t)nTris * sizeof(LeafTri), hipMemcpyDeviceToHost));
-            makeProjTris(lt, pt);
-            if ((rc = upload(ctx, ctx->projTris, pt.data(), pt.size())) != KKD_OK) return rc;
+        if (projTest) {
+            /* the TriAccel table follows the leaf order: one more kernel over the leaf records (same arithmetic as makeProjTris) */
+            e = ctx->projTris.ensure((size_t)nTris * sizeof(ProjTri));
+            if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? KKD_ERR_NOMEM : KKD_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+            gpuMakeProjTris(ctx->stream, (const LeafTri *)ctx->tris.p, nTris, (ProjTri *)ctx->projTris.p);
+            KKD_HIP(ctx, hipGetLastError());
             KKD_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
     }
     DScene &d = ctx->ds;
     std::memset(&d, 0, sizeof(d));
     d.nodes = (const Node4 *)ctx->nodes.p; d.tris = (const LeafTri *)ctx->tris.p; d.wideNodes = (const WideNode *)ctx->wideNodes.p;
-    d.projTris = (ctx->cfg.flags & KKD_FLAG_PROJECTION_TEST) ? (const ProjTri *)ctx->projTris.p : nullptr;
+    d.projTris = projTest ? (const ProjTri *)ctx->projTris.p : nullptr;
     d.positions = (const float *)ctx->positions.p; d.normals = (const float *)ctx->normals.p; d.texcoords = (const float *)ctx->texcoords.p;
     d.indices = (const uint32_t *)ctx->indices.p;
     d.shapes = (const DShape *)ctx->shapes.p; d.materials = (const DMaterial *)ctx->materials.p; d.emitters = (const DEmitter *)ctx->emitters.p;

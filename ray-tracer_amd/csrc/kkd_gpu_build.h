@@ -18,4 +18,8 @@ struct GpuBuildResult {
 hipError_t gpuBuildBvh(hipStream_t st, const float *dPos, const uint32_t *dIdx, uint32_t nTris, const DShape *dShapes, uint32_t nShapes,
                        Node4 *dNodes, WideNode *dWide, LeafTri *dTris, uint32_t nodeCapacity, GpuBuildResult *out, std::string &err);
 
+/* TriAccel records (kkd_bvh.cpp: makeProjTris, the reference's triaccel.h) for nTris leaf records, both on the device; same
+ * single-precision operations in the same order as the host version, so the two tables are bit-equal. */
+void gpuMakeProjTris(hipStream_t st, const LeafTri *dTris, uint32_t nTris, ProjTri *dProj);
+
 } /* namespace kkd */

@@ -232,6 +232,34 @@ __global__ void __launch_bounds__(256) kLeafTris(const float *__restrict__ pos, 
     tris[k] = t;
 }
 
+/* makeProjTris (kkd_bvh.cpp) on the device: every operation rounded on its own (no contraction), IEEE division */
+__global__ void __launch_bounds__(256) kProjTris(const LeafTri *__restrict__ tris, uint32_t n, ProjTri *__restrict__ out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const LeafTri t = tris[i];
+    ProjTri r; r.n_u = r.n_v = r.n_d = 0.f; r.k = 0u; r.a_u = r.a_v = r.b_nu = r.b_nv = 0.f; r.c_nu = r.c_nv = 0.f; r.pad[0] = r.pad[1] = 0u;
+    const float A[3] = { t.v0x, t.v0y, t.v0z };
+    const float b[3] = { __fsub_rn(t.v2x, t.v0x), __fsub_rn(t.v2y, t.v0y), __fsub_rn(t.v2z, t.v0z) };
+    const float c[3] = { __fsub_rn(t.v1x, t.v0x), __fsub_rn(t.v1y, t.v0y), __fsub_rn(t.v1z, t.v0z) };
+    const float N[3] = { __fsub_rn(__fmul_rn(c[1], b[2]), __fmul_rn(c[2], b[1])), __fsub_rn(__fmul_rn(c[2], b[0]), __fmul_rn(c[0], b[2])),
+                         __fsub_rn(__fmul_rn(c[0], b[1]), __fmul_rn(c[1], b[0])) };
+    uint32_t k = 0;
+    if (fabsf(N[1]) > fabsf(N[k])) k = 1;
+    if (fabsf(N[2]) > fabsf(N[k])) k = 2;
+    const uint32_t u = k == 2u ? 0u : k + 1u, v = u == 2u ? 0u : u + 1u;      /* waldModulo: (k + 1) % 3, (k + 2) % 3 */
+    auto pick = [](const float *a, uint32_t j) { return j == 0u ? a[0] : (j == 1u ? a[1] : a[2]); };
+    const float n_k = pick(N, k), bu = pick(b, u), bv = pick(b, v), cu = pick(c, u), cv = pick(c, v);
+    const float denom = __fsub_rn(__fmul_rn(bu, cv), __fmul_rn(bv, cu));
+    if (denom == 0.f) { r.k = 3u; out[i] = r; return; }
+    r.k = k;
+    r.n_u = __fdiv_rn(pick(N, u), n_k); r.n_v = __fdiv_rn(pick(N, v), n_k);
+    r.n_d = __fdiv_rn(__fadd_rn(__fadd_rn(__fmul_rn(A[0], N[0]), __fmul_rn(A[1], N[1])), __fmul_rn(A[2], N[2])), n_k);
+    r.b_nu = __fdiv_rn(bu, denom); r.b_nv = __fdiv_rn(-bv, denom);
+    r.a_u = pick(A, u); r.a_v = pick(A, v);
+    r.c_nu = __fdiv_rn(cv, denom); r.c_nv = __fdiv_rn(-cu, denom);
+    out[i] = r;
+}
+
 struct Scratch {
     std::vector<void *> ptrs;
     ~Scratch() { for (void *p : ptrs) hipFree(p); }
@@ -306,6 +334,10 @@ hipError_t gpuBuildBvh(hipStream_t st, const float *dPos, const uint32_t *dIdx, 
         for (int a = 0; a < 3; ++a) { out->cmin[a] = fromOrderedBits(hostWork[a]); out->cmax[a] = fromOrderedBits(hostWork[3 + a]); }
     }
     return hipSuccess;
+}
+
+void gpuMakeProjTris(hipStream_t st, const LeafTri *dTris, uint32_t nTris, ProjTri *dProj) {
+    if (nTris) hipLaunchKernelGGL(kProjTris, dim3((nTris + 255u) / 256u), dim3(256), 0, st, dTris, nTris, dProj);
 }
 
 } /* namespace kkd */

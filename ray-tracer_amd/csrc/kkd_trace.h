@@ -225,8 +225,12 @@ struct Walk {
                     const float4 a = tp[0], b = tp[1], c = tp[2];
                     float t, u, v;
                     bool done = false;
-                    if (PROJ ? projIntersect(ox, oy, oz, ray.dx, ray.dy, ray.dz, a, b, c, tmin, tmax, t, u, v)
-                             : woopIntersect(wr, ox, oy, oz, a, b, c, tmin, tmax, t, u, v)) {
+                    /* of two triangles hit at the same distance the one in the lower slot is reported, whatever the order in which
+                     * the walk reaches them: the packet walk's order depends on the other rays of the wave, and a render cut
+                     * into tiles or sample ranges groups the rays differently (coplanar emitters made 4 pixels of C3 differ) */
+                    if ((PROJ ? projIntersect(ox, oy, oz, ray.dx, ray.dy, ray.dz, a, b, c, tmin, tmax, t, u, v)
+                              : woopIntersect(wr, ox, oy, oz, a, b, c, tmin, tmax, t, u, v))
+                        && (ANY || t < tmax || hit.id == kNoHit || slot < hit.id)) {
                         tmax = t; hit.t = t; hit.u = u; hit.v = v; hit.id = slot;
                         done = ANY;
                     }
@@ -332,8 +336,9 @@ __device__ __forceinline__ void packetWalk(const WideNode *__restrict__ wnodes, 
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     float t, u, v;
-                    if (PROJ ? projIntersect(ray[r].ox, ray[r].oy, ray[r].oz, ray[r].dx, ray[r].dy, ray[r].dz, a, b, c, tmin[r], tmax[r], t, u, v)
-                             : woopIntersect(wr[r], ray[r].ox, ray[r].oy, ray[r].oz, a, b, c, tmin[r], tmax[r], t, u, v)) {
+                    if ((PROJ ? projIntersect(ray[r].ox, ray[r].oy, ray[r].oz, ray[r].dx, ray[r].dy, ray[r].dz, a, b, c, tmin[r], tmax[r], t, u, v)
+                              : woopIntersect(wr[r], ray[r].ox, ray[r].oy, ray[r].oz, a, b, c, tmin[r], tmax[r], t, u, v))
+                        && (t < tmax[r] || hit[r].id == kNoHit || start + i < hit[r].id)) {      /* equal distances: the lower slot, as in Walk::run */
                         tmax[r] = t; hit[r].t = t; hit[r].u = u; hit[r].v = v; hit[r].id = start + i;
                     }
                 }

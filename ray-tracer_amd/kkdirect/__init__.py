@@ -45,9 +45,9 @@ def device_count():
 class Context:
     """One kkd_ctx: one GPU, one uploaded scene."""
 
-    def __init__(self, device=0, seed=1, max_samples_in_flight=0, count_traversal=False, projection_test=False, one_lane=False, gpu_build=False):
+    def __init__(self, device=0, seed=1, max_samples_in_flight=0, count_traversal=False, projection_test=True, one_lane=False, gpu_build=False):
         self.lib = load_library()
-        cfg = abi.Config(device, (abi.FLAG_COUNT_TRAVERSAL if count_traversal else 0) | (abi.FLAG_PROJECTION_TEST if projection_test else 0) | (abi.FLAG_ONE_LANE if one_lane else 0) | (abi.FLAG_GPU_BUILD if gpu_build else 0),
+        cfg = abi.Config(device, (abi.FLAG_COUNT_TRAVERSAL if count_traversal else 0) | (0 if projection_test else abi.FLAG_WATERTIGHT_TEST) | (abi.FLAG_ONE_LANE if one_lane else 0) | (abi.FLAG_GPU_BUILD if gpu_build else 0),
                          seed, max_samples_in_flight)
         self.h = self.lib.kkd_create(C.byref(cfg))
         if not self.h:
@@ -166,11 +166,11 @@ class Context:
 class MultiContext:
     """One kkd_multi: several GPUs of one node behind one handle (tile-sharded or sample-split, include/kkdirect.h)."""
 
-    def __init__(self, devices, split="tile", seed=1, max_samples_in_flight=0, projection_test=False, gpu_build=False):
+    def __init__(self, devices, split="tile", seed=1, max_samples_in_flight=0, projection_test=True, gpu_build=False):
         self.lib = load_library()
         self._devs = (abi.i32 * len(devices))(*devices)
         cfg = abi.MultiConfig(len(devices), {"tile": abi.SPLIT_TILE, "sample": abi.SPLIT_SAMPLE}[split], self._devs,
-                              (abi.FLAG_PROJECTION_TEST if projection_test else 0) | (abi.FLAG_GPU_BUILD if gpu_build else 0), 0, seed, max_samples_in_flight)
+                              (0 if projection_test else abi.FLAG_WATERTIGHT_TEST) | (abi.FLAG_GPU_BUILD if gpu_build else 0), 0, seed, max_samples_in_flight)
         self.h = self.lib.kkd_multi_create(C.byref(cfg))
         if not self.h:
             raise KKDError(abi.KKD_ERR_DEVICE, self.lib.kkd_multi_last_error(None).decode())

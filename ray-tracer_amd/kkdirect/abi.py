@@ -16,6 +16,7 @@ RFILTER_GAUSSIAN, RFILTER_BOX, RFILTER_TENT, RFILTER_MITCHELL, RFILTER_CATMULLRO
 SHAPE_HAS_NORMALS, SHAPE_HAS_TEXCOORDS = 1, 2
 FLAG_COUNT_TRAVERSAL = 1
 FLAG_PROJECTION_TEST = 2
+FLAG_WATERTIGHT_TEST = 16
 FLAG_ONE_LANE = 4
 FLAG_GPU_BUILD = 8
 NOALLOC_MAX_RAYS = 1 << 30      # KKD_NOALLOC_MAX_RAYS
