@@ -373,6 +373,13 @@ int kkd_develop(kkd_ctx *ctx, const float *film, uint32_t width, uint32_t height
  * size, "-1" for little endian, then the scanlines bottom-up as float32.  Host only, no context needed. */
 int kkd_write_pfm(const char *path, const float *pixels, uint32_t width, uint32_t height, int32_t pixel_format);
 
+/* Bitmap::writeRGBE (src/libcore/bitmap.cpp:3679-3736; HDRFilm fileFormat = "rgbe", src/films/hdrfilm.cpp:224-225, 314-324:
+ * pixel format forced to RGB float32): "#?RGBE", "FORMAT=32-bit_rle_rgbe", "-Y h +X w", then every scanline as four
+ * run-length-encoded byte planes (R, G, B, shared exponent; RGBE_FromFloat / RGBE_WriteBytes_RLE, bitmap.cpp:3492-3576), flat
+ * pixels when the width is below 8 or above 32767.  pixel_format: KKD_PIXEL_RGB or KKD_PIXEL_RGBA (alpha is skipped).  No
+ * metadata comments (what the reference writes without annotations and with attachLog = false).  Host only. */
+int kkd_write_rgbe(const char *path, const float *pixels, uint32_t width, uint32_t height, int32_t pixel_format);
+
 /* MFilm::develop with fileFormat = numpy (src/films/mfilm.cpp:336-352): a version-1.0 .npy file holding a C-ordered
  * little-endian float32 array of shape (height, width, channels), or (height, width) when channels == 1, as
  * cnpy::npy_save writes it.  Host only, no context needed. */

@@ -263,6 +263,78 @@ def pfm_bytes(pixels):
     return head + np.ascontiguousarray(body).astype("<f4").tobytes()
 
 
+def rgbe_bytes(pixels):
+    """Bitmap::writeRGBE (reference src/libcore/bitmap.cpp:3679-3736) with RGBE_FromFloat (:3492-3508) and RGBE_WriteBytes_RLE
+    (:3524-3572), no metadata.  pixels: H x W x {3, 4} float32.  Pure Python: small images only."""
+    px = np.asarray(pixels, np.float32)
+    h, w, c = px.shape
+    if c not in (3, 4):
+        raise ValueError("writeRGBE(): pixel format must be ERGB or ERGBA")
+    out = bytearray(("#?RGBE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w)).encode())
+
+    def from_float(d):
+        mx = np.float32(max(d[0], d[1], d[2]))
+        if mx < np.float32(1e-32):
+            return (0, 0, 0, 0)
+        m, e = np.frexp(mx)
+        s = np.float32(np.float32(np.float32(m) * np.float32(256)) / mx)
+        return (int(np.float32(d[0] * s)) & 255, int(np.float32(d[1] * s)) & 255, int(np.float32(d[2] * s)) & 255, (int(e) + 128) & 255)
+
+    def rle(data):
+        n = len(data); cur = 0
+        while cur < n:
+            beg = cur; run = 0; old = 0
+            while run < 4 and beg < n:
+                beg += run; old = run; run = 1
+                while beg + run < n and run < 127 and data[beg] == data[beg + run]:
+                    run += 1
+            if old > 1 and old == beg - cur:
+                out.extend((128 + old, data[cur])); cur = beg
+            while cur < beg:
+                k = min(beg - cur, 128)
+                out.append(k); out.extend(data[cur:cur + k]); cur += k
+            if run >= 4:
+                out.extend((128 + run, data[beg])); cur += run
+
+    if w < 8 or w > 0x7fff:
+        for y in range(h):
+            for x in range(w):
+                out.extend(from_float(px[y, x]))
+    else:
+        for y in range(h):
+            out.extend((2, 2, w >> 8, w & 0xFF))
+            q = [from_float(px[y, x]) for x in range(w)]
+            for i in range(4):
+                rle([v[i] for v in q])
+    return bytes(out)
+
+
+def rgbe_decode(blob):
+    """reader for the files above (RGBE_ToFloat, bitmap.cpp:3510-3518, plus the standard scanline RLE) -> H x W x 3 float32"""
+    pos = blob.index(b"-Y ")
+    end = blob.index(b"\n", pos)
+    h, w = [int(t) for t in blob[pos:end].decode().replace("-Y", "").replace("+X", "").split()]
+    p = end + 1
+    img = np.zeros((h, w, 4), np.uint8)
+    if w < 8 or w > 0x7fff:
+        img[:] = np.frombuffer(blob[p:p + 4 * w * h], np.uint8).reshape(h, w, 4); p += 4 * w * h
+    else:
+        for y in range(h):
+            assert blob[p] == 2 and blob[p + 1] == 2 and (blob[p + 2] << 8 | blob[p + 3]) == w
+            p += 4
+            for i in range(4):
+                x = 0
+                while x < w:
+                    k = blob[p]; p += 1
+                    if k > 128:
+                        img[y, x:x + k - 128, i] = blob[p]; p += 1; x += k - 128
+                    else:
+                        img[y, x:x + k, i] = np.frombuffer(blob[p:p + k], np.uint8); p += k; x += k
+    assert p == len(blob)
+    f = np.where(img[..., 3:4] > 0, np.ldexp(np.float32(1.0), img[..., 3:4].astype(np.int32) - 136), 0).astype(np.float32)
+    return img[..., :3].astype(np.float32) * f
+
+
 # ---- on-disk mesh formats (the step right before the path; ORACLE = test infrastructure only) ---------------------
 import struct as _struct
 import zlib as _zlib

@@ -643,6 +643,66 @@ int kkd_write_pfm(const char *path, const float *pixels, uint32_t width, uint32_
     return ok ? KKD_OK : KKD_ERR_INVALID;
 }
 
+/* Bitmap::writeRGBE (src/libcore/bitmap.cpp:3679-3736) with RGBE_FromFloat (:3492-3508) and RGBE_WriteBytes_RLE (:3524-3572) */
+namespace {
+inline void rgbeFromFloat(const float *data, uint8_t rgbe[4]) {
+    float mx = std::max(std::max(data[0], data[1]), data[2]);
+    if (mx < 1e-32f) { rgbe[0] = rgbe[1] = rgbe[2] = rgbe[3] = 0; return; }
+    int e;
+    mx = std::frexp(mx, &e) * 256.0f / mx;
+    rgbe[0] = (uint8_t)(data[0] * mx); rgbe[1] = (uint8_t)(data[1] * mx); rgbe[2] = (uint8_t)(data[2] * mx);
+    rgbe[3] = (uint8_t)(e + 128);
+}
+inline void rgbeWriteRle(std::vector<uint8_t> &out, const uint8_t *data, int numbytes) {
+    int cur = 0;
+    while (cur < numbytes) {
+        int begRun = cur, runCount = 0, oldRunCount = 0;
+        while (runCount < 4 && begRun < numbytes) {                       /* the next run of at least 4, if there is one */
+            begRun += runCount; oldRunCount = runCount; runCount = 1;
+            while (begRun + runCount < numbytes && runCount < 127 && data[begRun] == data[begRun + runCount]) runCount++;
+        }
+        if (oldRunCount > 1 && oldRunCount == begRun - cur) {             /* a short run right before it */
+            out.push_back((uint8_t)(128 + oldRunCount)); out.push_back(data[cur]);
+            cur = begRun;
+        }
+        while (cur < begRun) {                                            /* literal bytes up to the run */
+            const int n = std::min(begRun - cur, 128);
+            out.push_back((uint8_t)n); out.insert(out.end(), data + cur, data + cur + n);
+            cur += n;
+        }
+        if (runCount >= 4) { out.push_back((uint8_t)(128 + runCount)); out.push_back(data[begRun]); cur += runCount; }
+    }
+}
+}
+int kkd_write_rgbe(const char *path, const float *pixels, uint32_t width, uint32_t height, int32_t pixel_format) {
+    if (!path || (!pixels && (uint64_t)width * height != 0)) return KKD_ERR_INVALID;
+    if (pixel_format != KKD_PIXEL_RGB && pixel_format != KKD_PIXEL_RGBA) return KKD_ERR_INVALID;   /* "pixel format must be ERGB or ERGBA" */
+    const int ch = pixel_format == KKD_PIXEL_RGB ? 3 : 4;
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return KKD_ERR_INVALID;
+    std::vector<uint8_t> out;
+    const std::string head = "#?RGBE\nFORMAT=32-bit_rle_rgbe\n\n-Y " + std::to_string(height) + " +X " + std::to_string(width) + "\n";
+    out.insert(out.end(), head.begin(), head.end());
+    const float *data = pixels;
+    if (width < 8 || width > 0x7fff) {                                    /* run-length encoding is not allowed: flat pixels */
+        for (size_t i = 0; i < (size_t)width * height; ++i, data += ch) { uint8_t q[4]; rgbeFromFloat(data, q); out.insert(out.end(), q, q + 4); }
+    } else {
+        std::vector<uint8_t> buffer((size_t)4 * width);
+        for (uint32_t y = 0; y < height; ++y) {
+            const uint8_t mark[4] = { 2, 2, (uint8_t)(width >> 8), (uint8_t)(width & 0xFF) };
+            out.insert(out.end(), mark, mark + 4);
+            for (uint32_t x = 0; x < width; ++x, data += ch) {
+                uint8_t q[4]; rgbeFromFloat(data, q);
+                buffer[x] = q[0]; buffer[width + x] = q[1]; buffer[2 * (size_t)width + x] = q[2]; buffer[3 * (size_t)width + x] = q[3];
+            }
+            for (int i = 0; i < 4; ++i) rgbeWriteRle(out, &buffer[(size_t)i * width], (int)width);
+        }
+    }
+    bool ok = std::fwrite(out.data(), 1, out.size(), f) == out.size();
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? KKD_OK : KKD_ERR_INVALID;
+}
+
 /* MFilm::develop, numpy branch (src/films/mfilm.cpp:336-352): cnpy::npy_save of a float array, shape (H, W[, C]) */
 int kkd_write_npy(const char *path, const float *pixels, uint32_t width, uint32_t height, uint32_t channels) {
     if (!path || channels == 0 || (!pixels && (uint64_t)width * height != 0)) return KKD_ERR_INVALID;

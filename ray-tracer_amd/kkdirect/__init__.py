@@ -258,6 +258,17 @@ def write_pfm(path, pixels, pixel_format=None):
         raise KKDError(rc, "kkd_write_pfm(%s) failed" % path)
 
 
+def write_rgbe(path, pixels):
+    """Bitmap::writeRGBE (reference src/libcore/bitmap.cpp:3679-3736) through kkd_write_rgbe; pixels H x W x {3, 4}."""
+    px = np.ascontiguousarray(pixels, np.float32)
+    if px.ndim != 3 or px.shape[2] not in (3, 4):
+        raise KKDError(abi.KKD_ERR_INVALID, "writeRGBE(): pixel format must be ERGB or ERGBA")
+    h, w, c = px.shape
+    rc = load_library().kkd_write_rgbe(os.fsencode(path), px.ctypes.data_as(abi.pf32), w, h, abi.PIXEL_RGB if c == 3 else abi.PIXEL_RGBA)
+    if rc != 0:
+        raise KKDError(rc, "kkd_write_rgbe(%s) failed" % path)
+
+
 def write_npy(path, pixels):
     """MFilm's numpy output (reference src/films/mfilm.cpp:336-352) through kkd_write_npy; pixels H x W [x C]."""
     px = np.ascontiguousarray(pixels, np.float32)

@@ -132,6 +132,7 @@ ENTRY_POINTS = {
     "kkd_develop": (C.c_int, [C.c_void_p, pf32, u32, u32, i32, pf32]),
     "kkd_write_pfm": (C.c_int, [C.c_char_p, pf32, u32, u32, i32]),
     "kkd_write_npy": (C.c_int, [C.c_char_p, pf32, u32, u32, u32]),
+    "kkd_write_rgbe": (C.c_int, [C.c_char_p, pf32, u32, u32, i32]),
     "kkd_parse_bsdf_stream": (C.c_int, [C.c_void_p, u64, C.POINTER(Material), u32, pu32]),
     "kkd_mesh_count_serialized": (C.c_int, [C.c_char_p, pu32]),
     "kkd_mesh_load_serialized": (C.c_int, [C.c_char_p, i32, pf32, C.POINTER(Mesh)]),

@@ -30,6 +30,31 @@ def test_write_pfm_bytes(tmp_path, shape):
     assert path.read_bytes() == kkoracle.pfm_bytes(img)
 
 
+@pytest.mark.parametrize("shape", [(5, 12, 3), (4, 9, 4), (3, 5, 3), (2, 300, 3)])
+def test_write_rgbe_bytes(tmp_path, shape):
+    """HDRFilm fileFormat = rgbe (reference src/libcore/bitmap.cpp:3679-3736): byte-equal with the restatement of the
+    reference's writer, for RLE scanlines (runs, short runs, literals over 128 bytes) and the flat layout of narrow images;
+    decoded again, every pixel is within the format's resolution (8-bit mantissa under the shared exponent)"""
+    rng = np.random.RandomState(sum(shape))
+    img = (rng.rand(*shape) ** 4 * 50).astype(np.float32)
+    img[0, : shape[1] // 2] = 0.25                      # a long run
+    img[1, 2:4] = img[1, 1]                             # a short run before literals
+    img[-1, -1, :3] = 0                                 # a black pixel: exponent byte 0
+    path = tmp_path / "x.rgbe"
+    kkdirect.write_rgbe(str(path), img)
+    blob = path.read_bytes()
+    assert blob == kkoracle.rgbe_bytes(img)
+    back = kkoracle.rgbe_decode(blob)
+    mx = img[..., :3].max(-1, keepdims=True)
+    assert (np.abs(back - img[..., :3]) <= mx / 128 + 1e-30).all() and (back <= img[..., :3] + 1e-30).all()   # truncating quantiser
+    assert blob.startswith(b"#?RGBE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (shape[0], shape[1]))
+
+
+def test_write_rgbe_rejects_other_formats(tmp_path):
+    with pytest.raises(kkdirect.KKDError):
+        kkdirect.write_rgbe(str(tmp_path / "x.rgbe"), np.zeros((2, 2, 1), np.float32))
+
+
 def test_write_pfm_rejects_other_formats(tmp_path):
     with pytest.raises(kkdirect.KKDError):
         kkdirect.write_pfm(str(tmp_path / "x.pfm"), np.zeros((2, 2, 2), np.float32))          # luminanceAlpha: not a PFM format
