@@ -380,6 +380,21 @@ int kkd_write_pfm(const char *path, const float *pixels, uint32_t width, uint32_
  * metadata comments (what the reference writes without annotations and with attachLog = false).  Host only. */
 int kkd_write_rgbe(const char *path, const float *pixels, uint32_t width, uint32_t height, int32_t pixel_format);
 
+/* Bitmap::writeOpenEXR (src/libcore/bitmap.cpp:3171-3318; HDRFilm's default fileFormat, src/films/hdrfilm.cpp:213-223, with
+ * componentFormat float16 by default): a single-part scanline OpenEXR 2 file with the header Imf::Header(width, height) carries
+ * (channels, compression, dataWindow, displayWindow, lineOrder = increasing y, pixelAspectRatio 1, screenWindowCenter 0 0,
+ * screenWindowWidth 1), the attribute "generatedBy", chromaticities as bitmap.cpp:3223-3231 adds them (Rec. 709 for RGB, the XYZ
+ * primaries for XYZ), channels Y | R G B (+ A) stored in alphabetical order, ZIP compression in blocks of 16 scanlines
+ * (Imf::Header's default) or none.  The OpenEXR library (third party, not in the checkout, not installed here) is replaced by
+ * a writer that follows the published file layout; no OpenEXR reader is available to check the files against, parity unpinned.
+ * component_format: KKD_COMPONENT_FLOAT16 (round to nearest even, as half.h) or KKD_COMPONENT_FLOAT32.  Host only. */
+#define KKD_COMPONENT_FLOAT16 0
+#define KKD_COMPONENT_FLOAT32 1
+#define KKD_EXR_NO_COMPRESSION 0
+#define KKD_EXR_ZIP_COMPRESSION 3
+int kkd_write_exr(const char *path, const float *pixels, uint32_t width, uint32_t height, int32_t pixel_format,
+                  int32_t component_format, int32_t compression, const char *generated_by);
+
 /* MFilm::develop with fileFormat = numpy (src/films/mfilm.cpp:336-352): a version-1.0 .npy file holding a C-ordered
  * little-endian float32 array of shape (height, width, channels), or (height, width) when channels == 1, as
  * cnpy::npy_save writes it.  Host only, no context needed. */

@@ -335,6 +335,105 @@ def rgbe_decode(blob):
     return img[..., :3].astype(np.float32) * f
 
 
+_EXR_CHANNELS = {"luminance": [("Y", 0)], "luminancealpha": [("A", 1), ("Y", 0)], "rgb": [("B", 2), ("G", 1), ("R", 0)],
+                 "rgba": [("A", 3), ("B", 2), ("G", 1), ("R", 0)], "xyz": [("B", 2), ("G", 1), ("R", 0)], "xyza": [("A", 3), ("B", 2), ("G", 1), ("R", 0)]}
+
+
+def exr_bytes(pixels, pixel_format="rgb", component_format="float16", compression="zip", generated_by="kkdirect"):
+    """Bitmap::writeOpenEXR (reference src/libcore/bitmap.cpp:3171-3318) without the OpenEXR library (third party, absent):
+    the published single-part scanline layout, attributes in the order of Imf::Header's map, ZIP in blocks of 16 lines.
+    numpy's float16 cast rounds to nearest even like half.h.  Parity with files written by OpenEXR itself is unpinned."""
+    import struct, zlib
+    px = np.asarray(pixels, np.float32)
+    if px.ndim == 2:
+        px = px[..., None]
+    h, w, _ = px.shape
+    chans = _EXR_CHANNELS[pixel_format]
+    half = component_format == "float16"
+
+    def attr(name, typ, value):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(value)) + value
+
+    out = bytearray(b"\x76\x2f\x31\x01" + struct.pack("<i", 2))
+    out += attr("channels", "chlist", b"".join(n.encode() + b"\0" + struct.pack("<iB3xii", 1 if half else 2, 0, 1, 1) for n, _ in chans) + b"\0")
+    if pixel_format in ("rgb", "rgba"):
+        out += attr("chromaticities", "chromaticities", struct.pack("<8f", 0.64, 0.33, 0.30, 0.60, 0.15, 0.06, 0.3127, 0.3290))
+    elif pixel_format in ("xyz", "xyza"):
+        out += attr("chromaticities", "chromaticities", struct.pack("<8f", 1.0, 0.0, 0.0, 1.0, 0.0, 0.0, np.float32(1.0) / np.float32(3.0), np.float32(1.0) / np.float32(3.0)))
+    comp = {"none": 0, "zip": 3}[compression]
+    out += attr("compression", "compression", bytes([comp]))
+    box = struct.pack("<4i", 0, 0, w - 1, h - 1)
+    out += attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box)
+    out += attr("generatedBy", "string", generated_by.encode())
+    out += attr("lineOrder", "lineOrder", b"\0") + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+    out += attr("screenWindowCenter", "v2f", struct.pack("<2f", 0.0, 0.0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+    lines = 16 if comp == 3 else 1
+    n_chunks = (h + lines - 1) // lines
+    table = len(out)
+    out += b"\0" * (8 * n_chunks)
+    for c in range(n_chunks):
+        y0, y1 = c * lines, min(h, (c + 1) * lines)
+        with np.errstate(over="ignore"):                       # values beyond the half range become inf, as in half.h
+            raw = b"".join(np.ascontiguousarray(px[y, :, src]).astype("<f2" if half else "<f4").tobytes() for y in range(y0, y1) for _, src in chans)
+        data = raw
+        if comp == 3:
+            a = np.frombuffer(raw, np.uint8)
+            t = np.concatenate([a[0::2], a[1::2]]).astype(np.int32)
+            t[1:] = (t[1:] - t[:-1] + 384) & 255
+            z = zlib.compress(t.astype(np.uint8).tobytes())
+            if len(z) < len(raw):
+                data = z
+        struct.pack_into("<Q", out, table + 8 * c, len(out))
+        out += struct.pack("<ii", y0, len(data)) + data
+    return bytes(out)
+
+
+def exr_decode(blob):
+    """reader for single-part scanline files with no or ZIP compression -> (dict of attributes, {channel: H x W float32})"""
+    import struct, zlib
+    assert blob[:4] == b"\x76\x2f\x31\x01" and struct.unpack_from("<i", blob, 4)[0] == 2
+    p = 8; attrs = {}
+    while blob[p] != 0:
+        e = blob.index(b"\0", p); name = blob[p:e].decode(); p = e + 1
+        e = blob.index(b"\0", p); typ = blob[p:e].decode(); p = e + 1
+        n = struct.unpack_from("<i", blob, p)[0]; p += 4
+        attrs[name] = (typ, blob[p:p + n]); p += n
+    p += 1
+    chans = []; v = attrs["channels"][1]; q = 0
+    while v[q] != 0:
+        e = v.index(b"\0", q); nm = v[q:e].decode(); q = e + 1
+        pt, lin, xs, ys = struct.unpack_from("<iB3xii", v, q); q += 16
+        assert xs == 1 and ys == 1
+        chans.append((nm, pt))
+    assert [c[0] for c in chans] == sorted(c[0] for c in chans)
+    x0, y0_, x1, y1_ = struct.unpack("<4i", attrs["dataWindow"][1]); w, h = x1 - x0 + 1, y1_ - y0_ + 1
+    comp = attrs["compression"][1][0]; lines = 16 if comp == 3 else 1
+    n_chunks = (h + lines - 1) // lines
+    offs = struct.unpack_from("<%dQ" % n_chunks, blob, p)
+    img = {nm: np.zeros((h, w), np.float32) for nm, _ in chans}
+    end = p + 8 * n_chunks
+    for c, o in enumerate(offs):
+        assert o == end                                    # chunks follow the table back to back, in increasing y
+        y, n = struct.unpack_from("<ii", blob, o); data = blob[o + 8:o + 8 + n]; end = o + 8 + n
+        assert y == c * lines
+        ny = min(h, y + lines) - y
+        size = ny * sum(w * (2 if pt == 1 else 4) for _, pt in chans)
+        if comp == 3 and n < size:
+            t = np.frombuffer(zlib.decompress(data), np.uint8).astype(np.int32)
+            t = (np.cumsum(np.concatenate([t[:1], t[1:] - 128])) & 255).astype(np.uint8)
+            half_n = (size + 1) // 2
+            a = np.empty(size, np.uint8); a[0::2] = t[:half_n]; a[1::2] = t[half_n:]
+            data = a.tobytes()
+        assert len(data) == size
+        q = 0
+        for yy in range(y, y + ny):
+            for nm, pt in chans:
+                k = w * (2 if pt == 1 else 4)
+                img[nm][yy] = np.frombuffer(data[q:q + k], "<f2" if pt == 1 else "<f4").astype(np.float32); q += k
+    assert end == len(blob)
+    return attrs, img
+
+
 # ---- on-disk mesh formats (the step right before the path; ORACLE = test infrastructure only) ---------------------
 import struct as _struct
 import zlib as _zlib

@@ -25,6 +25,7 @@
 #include <mutex>
 #include <thread>
 #include <tuple>
+#include <zlib.h>
 
 namespace kkd {
 
@@ -700,6 +701,102 @@ int kkd_write_rgbe(const char *path, const float *pixels, uint32_t width, uint32
     }
     bool ok = std::fwrite(out.data(), 1, out.size(), f) == out.size();
     ok = (std::fclose(f) == 0) && ok;
+    return ok ? KKD_OK : KKD_ERR_INVALID;
+}
+
+/* Bitmap::writeOpenEXR (src/libcore/bitmap.cpp:3171-3318) without the OpenEXR library: the published layout of a single-part
+ * scanline file -- magic, version 2, attributes in the order of Imf::Header's map (by name), line offset table, chunks of 1 (no
+ * compression) or 16 (ZIP) scanlines, each scanline channel by channel in alphabetical order; ZIP = byte de-interleave,
+ * delta predictor, deflate, kept only when smaller. */
+namespace {
+struct ExrBuf {
+    std::vector<uint8_t> b;
+    void u8(uint8_t v) { b.push_back(v); }
+    void i32(int32_t v) { for (int i = 0; i < 4; ++i) b.push_back((uint8_t)((uint32_t)v >> (8 * i))); }
+    void u64(uint64_t v) { for (int i = 0; i < 8; ++i) b.push_back((uint8_t)(v >> (8 * i))); }
+    void f32(float v) { uint32_t u; std::memcpy(&u, &v, 4); i32((int32_t)u); }
+    void str0(const char *s) { while (*s) b.push_back((uint8_t)*s++); b.push_back(0); }
+    void attr(const char *name, const char *type, const ExrBuf &value) { str0(name); str0(type); i32((int32_t)value.b.size()); b.insert(b.end(), value.b.begin(), value.b.end()); }
+};
+}
+int kkd_write_exr(const char *path, const float *pixels, uint32_t width, uint32_t height, int32_t pixel_format,
+                  int32_t component_format, int32_t compression, const char *generated_by) {
+    if (!path || !pixels || !width || !height || width > 0x3fffffffu || height > 0x3fffffffu) return KKD_ERR_INVALID;
+    if (component_format != KKD_COMPONENT_FLOAT16 && component_format != KKD_COMPONENT_FLOAT32) return KKD_ERR_INVALID;
+    if (compression != KKD_EXR_NO_COMPRESSION && compression != KKD_EXR_ZIP_COMPRESSION) return KKD_ERR_UNSUPPORTED;
+    /* channel names in file (= alphabetical) order with their position in the interleaved source pixel */
+    struct Ch { const char *name; int src; };
+    std::vector<Ch> chans; int nSrc;
+    switch (pixel_format) {
+        case KKD_PIXEL_LUMINANCE: chans = { { "Y", 0 } }; nSrc = 1; break;
+        case KKD_PIXEL_LUMINANCE_ALPHA: chans = { { "A", 1 }, { "Y", 0 } }; nSrc = 2; break;
+        case KKD_PIXEL_RGB: case KKD_PIXEL_XYZ: chans = { { "B", 2 }, { "G", 1 }, { "R", 0 } }; nSrc = 3; break;
+        case KKD_PIXEL_RGBA: case KKD_PIXEL_XYZA: chans = { { "A", 3 }, { "B", 2 }, { "G", 1 }, { "R", 0 } }; nSrc = 4; break;
+        default: return KKD_ERR_INVALID;
+    }
+    const bool half = component_format == KKD_COMPONENT_FLOAT16;
+    const size_t comp = half ? 2 : 4, lineBytes = (size_t)width * chans.size() * comp;
+    ExrBuf f;
+    f.u8(0x76); f.u8(0x2f); f.u8(0x31); f.u8(0x01);            /* magic 20000630 */
+    f.i32(2);                                                  /* version 2, no flags: single-part scanline */
+    { ExrBuf v; for (const Ch &c : chans) { v.str0(c.name); v.i32(half ? 1 : 2); v.u8(0); v.u8(0); v.u8(0); v.u8(0); v.i32(1); v.i32(1); } v.u8(0); f.attr("channels", "chlist", v); }
+    if (pixel_format >= KKD_PIXEL_RGB) {
+        ExrBuf v;
+        const bool xyz = pixel_format == KKD_PIXEL_XYZ || pixel_format == KKD_PIXEL_XYZA;
+        const float rec709[8] = { 0.64f, 0.33f, 0.30f, 0.60f, 0.15f, 0.06f, 0.3127f, 0.3290f };        /* Imf::Chromaticities() */
+        const float cie[8] = { 1.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 1.0f / 3.0f, 1.0f / 3.0f };         /* bitmap.cpp:3224-3228 */
+        for (int i = 0; i < 8; ++i) v.f32(xyz ? cie[i] : rec709[i]);
+        f.attr("chromaticities", "chromaticities", v);
+    }
+    { ExrBuf v; v.u8((uint8_t)compression); f.attr("compression", "compression", v); }
+    { ExrBuf v; v.i32(0); v.i32(0); v.i32((int32_t)width - 1); v.i32((int32_t)height - 1); f.attr("dataWindow", "box2i", v); f.attr("displayWindow", "box2i", v); }
+    { ExrBuf v; const char *g = generated_by ? generated_by : "kkdirect"; while (*g) v.u8((uint8_t)*g++); f.attr("generatedBy", "string", v); }
+    { ExrBuf v; v.u8(0); f.attr("lineOrder", "lineOrder", v); }
+    { ExrBuf v; v.f32(1.0f); f.attr("pixelAspectRatio", "float", v); }
+    { ExrBuf v; v.f32(0.0f); v.f32(0.0f); f.attr("screenWindowCenter", "v2f", v); }
+    { ExrBuf v; v.f32(1.0f); f.attr("screenWindowWidth", "float", v); }
+    f.u8(0);                                                   /* end of the header */
+    const uint32_t linesPerChunk = compression == KKD_EXR_ZIP_COMPRESSION ? 16u : 1u, nChunks = (height + linesPerChunk - 1) / linesPerChunk;
+    const size_t tablePos = f.b.size();
+    for (uint32_t c = 0; c < nChunks; ++c) f.u64(0);
+    std::vector<uint8_t> raw, tmp;
+    for (uint32_t c = 0; c < nChunks; ++c) {
+        const uint32_t y0 = c * linesPerChunk, y1 = std::min(height, y0 + linesPerChunk);
+        raw.clear(); raw.reserve((size_t)(y1 - y0) * lineBytes);
+        for (uint32_t y = y0; y < y1; ++y)
+            for (const Ch &ch : chans) {
+                const float *src = pixels + (size_t)y * width * nSrc + ch.src;
+                for (uint32_t x = 0; x < width; ++x, src += nSrc) {
+                    if (half) { const uint16_t h = kkd::floatToHalf(*src); raw.push_back((uint8_t)h); raw.push_back((uint8_t)(h >> 8)); }
+                    else { uint32_t u; std::memcpy(&u, src, 4); for (int i = 0; i < 4; ++i) raw.push_back((uint8_t)(u >> (8 * i))); }
+                }
+            }
+        const uint8_t *data = raw.data(); size_t n = raw.size();
+        std::vector<uint8_t> packed;
+        if (compression == KKD_EXR_ZIP_COMPRESSION) {
+            tmp.resize(n);
+            {   /* even bytes to the first half, odd bytes to the second */
+                size_t t1 = 0, t2 = (n + 1) / 2;
+                for (size_t i = 0; i < n; ++i) { if ((i & 1) == 0) tmp[t1++] = raw[i]; else tmp[t2++] = raw[i]; }
+            }
+            {   /* delta predictor */
+                int p = tmp[0];
+                for (size_t i = 1; i < n; ++i) { const int d = (int)tmp[i] - p + (128 + 256); p = tmp[i]; tmp[i] = (uint8_t)d; }
+            }
+            uLongf outLen = compressBound((uLong)n);
+            packed.resize(outLen);
+            if (compress(packed.data(), &outLen, tmp.data(), (uLong)n) != Z_OK) return KKD_ERR_INVALID;
+            if (outLen < n) { packed.resize(outLen); data = packed.data(); n = outLen; }      /* else: the chunk is stored as it is */
+        }
+        const uint64_t pos = f.b.size();
+        for (int i = 0; i < 8; ++i) f.b[tablePos + 8 * (size_t)c + i] = (uint8_t)(pos >> (8 * i));
+        f.i32((int32_t)y0); f.i32((int32_t)n);
+        f.b.insert(f.b.end(), data, data + n);
+    }
+    FILE *fp = std::fopen(path, "wb");
+    if (!fp) return KKD_ERR_INVALID;
+    bool ok = std::fwrite(f.b.data(), 1, f.b.size(), fp) == f.b.size();
+    ok = (std::fclose(fp) == 0) && ok;
     return ok ? KKD_OK : KKD_ERR_INVALID;
 }
 

@@ -269,6 +269,23 @@ def write_rgbe(path, pixels):
         raise KKDError(rc, "kkd_write_rgbe(%s) failed" % path)
 
 
+def write_exr(path, pixels, pixel_format=None, component_format="float16", compression="zip", generated_by=None):
+    """Bitmap::writeOpenEXR (reference src/libcore/bitmap.cpp:3171-3318) through kkd_write_exr; pixels H x W [x C];
+    pixel_format: name as in HDRFilm's 'pixelFormat' (default by channel count: luminance / luminanceAlpha / rgb / rgba)."""
+    px = np.ascontiguousarray(pixels, np.float32)
+    if px.ndim == 2:
+        px = px[..., None]
+    h, w, c = px.shape
+    fmt = abi.PIXEL_FORMATS[pixel_format.lower()] if pixel_format else {1: abi.PIXEL_LUMINANCE, 2: abi.PIXEL_LUMINANCE_ALPHA, 3: abi.PIXEL_RGB, 4: abi.PIXEL_RGBA}.get(c, -1)
+    if fmt < 0 or abi.PIXEL_CHANNELS[fmt] != c:
+        raise KKDError(abi.KKD_ERR_INVALID, "writeOpenEXR(): %d channels do not fit the pixel format" % c)
+    comp = {"float16": abi.COMPONENT_FLOAT16, "float32": abi.COMPONENT_FLOAT32}[component_format]
+    zc = {"zip": abi.EXR_ZIP_COMPRESSION, "none": abi.EXR_NO_COMPRESSION}[compression]
+    rc = load_library().kkd_write_exr(os.fsencode(path), px.ctypes.data_as(abi.pf32), w, h, fmt, comp, zc, generated_by.encode() if generated_by else None)
+    if rc != 0:
+        raise KKDError(rc, "kkd_write_exr(%s) failed" % path)
+
+
 def write_npy(path, pixels):
     """MFilm's numpy output (reference src/films/mfilm.cpp:336-352) through kkd_write_npy; pixels H x W [x C]."""
     px = np.ascontiguousarray(pixels, np.float32)

@@ -21,6 +21,8 @@ FLAG_ONE_LANE = 4
 FLAG_GPU_BUILD = 8
 NOALLOC_MAX_RAYS = 1 << 30      # KKD_NOALLOC_MAX_RAYS
 PIXEL_LUMINANCE, PIXEL_LUMINANCE_ALPHA, PIXEL_RGB, PIXEL_RGBA, PIXEL_XYZ, PIXEL_XYZA = range(6)
+COMPONENT_FLOAT16, COMPONENT_FLOAT32 = 0, 1
+EXR_NO_COMPRESSION, EXR_ZIP_COMPRESSION = 0, 3
 PIXEL_CHANNELS = {PIXEL_LUMINANCE: 1, PIXEL_LUMINANCE_ALPHA: 2, PIXEL_RGB: 3, PIXEL_RGBA: 4, PIXEL_XYZ: 3, PIXEL_XYZA: 4}
 PIXEL_FORMATS = {"luminance": PIXEL_LUMINANCE, "luminancealpha": PIXEL_LUMINANCE_ALPHA, "rgb": PIXEL_RGB, "rgba": PIXEL_RGBA,
                  "xyz": PIXEL_XYZ, "xyza": PIXEL_XYZA}
@@ -133,6 +135,7 @@ ENTRY_POINTS = {
     "kkd_write_pfm": (C.c_int, [C.c_char_p, pf32, u32, u32, i32]),
     "kkd_write_npy": (C.c_int, [C.c_char_p, pf32, u32, u32, u32]),
     "kkd_write_rgbe": (C.c_int, [C.c_char_p, pf32, u32, u32, i32]),
+    "kkd_write_exr": (C.c_int, [C.c_char_p, pf32, u32, u32, i32, i32, i32, C.c_char_p]),
     "kkd_parse_bsdf_stream": (C.c_int, [C.c_void_p, u64, C.POINTER(Material), u32, pu32]),
     "kkd_mesh_count_serialized": (C.c_int, [C.c_char_p, pu32]),
     "kkd_mesh_load_serialized": (C.c_int, [C.c_char_p, i32, pf32, C.POINTER(Mesh)]),

@@ -55,6 +55,42 @@ def test_write_rgbe_rejects_other_formats(tmp_path):
         kkdirect.write_rgbe(str(tmp_path / "x.rgbe"), np.zeros((2, 2, 1), np.float32))
 
 
+@pytest.mark.parametrize("fmt,ch", [("rgb", 3), ("rgba", 4), ("luminance", 1), ("luminancealpha", 2), ("xyz", 3), ("xyza", 4)])
+@pytest.mark.parametrize("component", ["float16", "float32"])
+@pytest.mark.parametrize("compression", ["zip", "none"])
+def test_write_exr(tmp_path, fmt, ch, component, compression):
+    """HDRFilm's default output (reference src/libcore/bitmap.cpp:3171-3318, src/films/hdrfilm.cpp:213-223).  The OpenEXR library
+    is absent, and so is any third-party reader: the file is compared byte for byte with the oracle's independent writer of
+    the published layout and read back with the oracle's reader -- header attributes, channel order, offsets, ZIP blocks of
+    16 lines with a partial last block, values equal to the float16 / float32 rounding of the input.  Parity unpinned."""
+    rng = np.random.RandomState(ch)
+    img = (rng.rand(37, 21, ch) ** 3 * 20).astype(np.float32)
+    img[5:30, :, 0] = 0.5                                   # compressible rows
+    img[0, 0] = 0; img[1, 1] = 70000.0                      # zero and a value beyond the half range (-> inf in float16)
+    path = tmp_path / "x.exr"
+    kkdirect.write_exr(str(path), img, pixel_format=fmt, component_format=component, compression=compression, generated_by="test")
+    blob = path.read_bytes()
+    assert blob == kkoracle.exr_bytes(img, fmt, component, compression, generated_by="test")
+    attrs, chans = kkoracle.exr_decode(blob)
+    names = {"rgb": "RGB", "rgba": "RGBA", "luminance": "Y", "luminancealpha": "YA", "xyz": "RGB", "xyza": "RGBA"}[fmt]
+    assert sorted(chans) == sorted(names)
+    with np.errstate(over="ignore"):
+        want = img.astype(np.float16).astype(np.float32) if component == "float16" else img
+    for k, nm in enumerate(names):
+        np.testing.assert_array_equal(chans[nm], want[..., k])
+    assert attrs["generatedBy"] == ("string", b"test") and attrs["lineOrder"][1] == b"\0" and attrs["compression"][1][0] == (3 if compression == "zip" else 0)
+    assert ("chromaticities" in attrs) == (ch >= 3)
+    if compression == "zip":
+        assert len(blob) < len(kkoracle.exr_bytes(img, fmt, component, "none", generated_by="test"))
+
+
+def test_write_exr_rejects_bad_arguments(tmp_path):
+    with pytest.raises(kkdirect.KKDError):
+        kkdirect.write_exr(str(tmp_path / "x.exr"), np.zeros((2, 2, 3), np.float32), pixel_format="rgba")
+    with pytest.raises(kkdirect.KKDError):
+        kkdirect.write_exr(str(tmp_path / "nodir" / "x.exr"), np.zeros((2, 2, 3), np.float32))
+
+
 def test_write_pfm_rejects_other_formats(tmp_path):
     with pytest.raises(kkdirect.KKDError):
         kkdirect.write_pfm(str(tmp_path / "x.pfm"), np.zeros((2, 2, 2), np.float32))          # luminanceAlpha: not a PFM format
