@@ -127,3 +127,51 @@ def test_kk_and_stock_direct_converge_to_the_same_image(gpu):
         c, _ = ctx.render(2048, 2, 2, sample_first=10_000)
     assert helpers.rel_mse(helpers.develop(a), helpers.develop(b)) <= 1e-3
     assert helpers.rel_mse(helpers.develop(c), helpers.develop(a)) <= 1e-3
+
+
+def _emitting_room(rho, Le, size=12):
+    """camera inside a closed box whose six walls are diffuse (rho) AND emit Le (faces point inwards)"""
+    sc = Scene()
+    v = np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], np.float32)
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]     # outward winding
+    idx = [t for a, b, c, d in quads for t in ((a, c, b), (a, d, c))]                                 # flipped: normals point in
+    sc.add_mesh(v, idx, sc.diffuse((rho,) * 3), radiance=Le)
+    sc.set_sensor(look_at((0.1, -0.2, 0.3), (1, 0.4, -0.2), (0, 1, 0)), 50.0, size, size, near=0.01, far=100.0)
+    return sc
+
+
+def test_emitting_enclosure_series(gpu):
+    """a closed enclosure with uniform emission Le and albedo rho has the uniform solution Le / (1 - rho) whatever its shape;
+    cut at n vertices it is Le (1 + rho + ... + rho^(n-1)).  kk and stock direct = two terms, path with maxDepth n = n terms, path
+    without a bound (Russian roulette from depth 3) = the limit.  Pins the area emitter (sampling, pdf, eval on hit), the
+    diffuse BSDF, both MIS weights, the depth rule of path.cpp:135-165 and the roulette -- without the oracle"""
+    rho, Le = 0.6, np.array([2.0, 1.0, 0.5])
+    sc = _emitting_room(rho, Le)
+    np.testing.assert_allclose(_mean_rgb(gpu, sc, 4096), Le * (1 + rho), rtol=ERROR_REQ)
+    np.testing.assert_allclose(_mean_rgb(gpu, sc, 2048, bsdf_samples=2, light_samples=3), Le * (1 + rho), rtol=ERROR_REQ)
+    np.testing.assert_allclose(_mean_rgb(gpu, sc, 4096, integrator=abi.INTEGRATOR_DIRECT), Le * (1 + rho), rtol=ERROR_REQ)
+    for n in (1, 2, 3, 6):
+        want = Le * sum(rho ** k for k in range(n))
+        np.testing.assert_allclose(_mean_rgb(gpu, sc, 4096, integrator=abi.INTEGRATOR_PATH, max_depth=n, rr_depth=100), want, rtol=ERROR_REQ)
+    np.testing.assert_allclose(_mean_rgb(gpu, sc, 8192, integrator=abi.INTEGRATOR_PATH, max_depth=-1, rr_depth=3), Le / (1 - rho), rtol=ERROR_REQ)
+    # hideEmitters removes exactly the directly visible term
+    np.testing.assert_allclose(_mean_rgb(gpu, sc, 4096, hide_emitters=True), Le * rho, rtol=ERROR_REQ)
+
+
+def test_glass_sphere_in_a_furnace(gpu):
+    """a non-absorbing dielectric under a constant environment L, path plugin without a depth bound: every path leaves the
+    sphere with throughput 1 (Fresnel-sampled lobes have weight 1, the radiance scaling (1 / eta)^2 on entry cancels eta^2 on
+    exit, dielectric.cpp:217-333), so EVERY pixel is L whatever the sample count -- no Monte Carlo noise at all without
+    roulette.  Pins the two delta lobes, the eta bookkeeping, total internal reflection and the tracer on a closed mesh."""
+    from kkdirect.scenes import cube_sphere
+    L = np.array([1.25, 0.75, 0.5], np.float32)
+    sc = Scene()
+    p, i = cube_sphere(24, 1.0, 0.0, 1)
+    sc.add_mesh(p, i, sc.dielectric(1.5), normals=compute_vertex_normals(p, i))
+    sc.set_envmap(np.tile(L, (8, 16, 1)))
+    sc.set_sensor(look_at((0, 0.3, -4), (0, 0, 0), (0, 1, 0)), 35.0, 32, 32, near=0.01, far=100.0)
+    with gpu.Context(device=0, seed=5).upload(sc) as ctx:
+        film, _ = ctx.render(8, integrator=abi.INTEGRATOR_PATH, max_depth=-1, rr_depth=100000)
+    img = helpers.develop(film)[2:-2, 2:-2].reshape(-1, 3)
+    # (a ray in a thousand runs along the faceted surface until the 4096-vertex bound of the path kernel cuts it)
+    assert (np.abs(img / L - 1) < 2e-3).mean() > 0.99 and abs(img.mean(0) / L - 1).max() < 2e-3
