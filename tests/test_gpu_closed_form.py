@@ -175,3 +175,56 @@ def test_glass_sphere_in_a_furnace(gpu):
     img = helpers.develop(film)[2:-2, 2:-2].reshape(-1, 3)
     # (a ray in a thousand runs along the faceted surface until the 4096-vertex bound of the path kernel cuts it)
     assert (np.abs(img / L - 1) < 2e-3).mean() > 0.99 and abs(img.mean(0) / L - 1).max() < 2e-3
+
+
+def _conductor_fresnel(c, eta, k):
+    """exact Fresnel reflectance of a conductor for unpolarised light (textbook form, written out here independently)"""
+    c2 = c * c; s2 = 1 - c2; s4 = s2 * s2
+    t1 = eta * eta - k * k - s2
+    a2pb2 = np.sqrt(t1 * t1 + 4 * k * k * eta * eta)
+    a = np.sqrt(0.5 * (a2pb2 + t1))
+    term1 = a2pb2 + c2; term2 = 2 * a * c
+    rs = (term1 - term2) / (term1 + term2)
+    term3 = a2pb2 * c2 + s4; term4 = term2 * s2
+    return 0.5 * (rs + rs * (term3 - term4) / (term3 + term4))
+
+
+def _microfacet_d_g1(distr, alpha):
+    if distr == abi.DISTR_BECKMANN:
+        def D(ct):
+            t2 = (1 - ct * ct) / (ct * ct)
+            return math.exp(-t2 / alpha ** 2) / (math.pi * alpha ** 2 * ct ** 4)
+        def G1(ct):
+            tan = math.sqrt(1 - ct * ct) / ct
+            if tan == 0: return 1.0
+            a = 1 / (alpha * tan)
+            return 1.0 if a >= 1.6 else (3.535 * a + 2.181 * a * a) / (1 + 2.276 * a + 2.577 * a * a)
+    else:
+        def D(ct):
+            t2 = (1 - ct * ct) / (ct * ct)
+            return 1 / (math.pi * alpha ** 2 * ct ** 4 * (1 + t2 / alpha ** 2) ** 2)
+        def G1(ct):
+            t2 = (1 - ct * ct) / (ct * ct)
+            return 2 / (1 + math.sqrt(1 + alpha * alpha * t2))
+    return D, G1
+
+
+@pytest.mark.parametrize("distr,alpha", [(abi.DISTR_BECKMANN, 0.3), (abi.DISTR_GGX, 0.25), (abi.DISTR_BECKMANN, 0.15)])
+@pytest.mark.parametrize("light_dir", [(0.5, 1.0, 0.2), (-0.3, 1.0, 0.9)])      # off-specular and near the mirror direction
+def test_rough_conductor_under_a_point_light(gpu, distr, alpha, light_dir):
+    """one point light, one viewing direction: Lo = F(wi.h) D(h) G1(wi) G1(wo) / (4 cos theta_view) * I / d^2 with h the
+    half vector -- the microfacet model of roughconductor.cpp:257-300 / microfacet.h evaluated here in plain Python from the
+    textbook formulas (Beckmann / GGX D, Smith G1 with Walter's rational fit for Beckmann, exact conductor Fresnel), not through
+    the oracle.  A point light has MIS weight 1 (kk/direct.cpp:152) and BSDF samples cannot reach it: the value is exact."""
+    eta = np.array([0.2, 0.92, 1.1]); k = np.array([3.9, 2.45, 2.14]); I = np.array([30.0, 30.0, 30.0]); ext = 1.000277
+    eye = np.array([0.0, 2.0, -2.5])
+    sc = _plane_scene(lambda s: s.roughconductor(eta, k, alpha=alpha, distribution=distr), eye=tuple(eye), fov=0.5, size=8)
+    lp = np.array(light_dir, float) * 3.0
+    sc.add_point_light(tuple(lp), I)
+    wv = eye / np.linalg.norm(eye); wl = lp / np.linalg.norm(lp)
+    h = wv + wl; h /= np.linalg.norm(h)
+    D, G1 = _microfacet_d_g1(distr, alpha)
+    F = _conductor_fresnel(float(wv @ h), eta / ext, k / ext)
+    want = F * D(h[1]) * G1(wv[1]) * G1(wl[1]) / (4 * wv[1]) * I / float(lp @ lp)
+    got = _mean_rgb(gpu, sc, 64)
+    np.testing.assert_allclose(got, want, rtol=ERROR_REQ)
