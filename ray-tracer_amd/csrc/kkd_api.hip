@@ -527,10 +527,13 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     const uint32_t g = std::min(64u, pow2ceil(rp->spp)), chunks = (rp->spp + g - 1) / g;
     uint32_t gShift = 0; while ((1u << gShift) < g) ++gShift;
     const uint64_t total = (uint64_t)nTilesMine * bs * bs * chunks * g;
-    /* library default: 16 M camera samples in flight per lane, fewer when every sample carries many BSDF / emitter samples
-     * (the ray and record buffers grow with max(bsdfSamples, lightSamples): ~0.2 KB per ray pair and lane) */
+    /* library default: 64 M camera samples in flight per lane, fewer when every sample carries many BSDF / emitter samples
+     * (the ray and record buffers grow with max(bsdfSamples, lightSamples): ~0.2 KB per ray pair and lane, 14 GB per lane at
+     * the default).  Every batch ends each of its traversal stages with a round that runs as long as the batch's longest
+     * ray, ~0.4 ms with the device nearly idle, so fewer, larger batches are faster: C4 2720 / 2796 / 2841 / 2885 / 2898 / 2903
+     * Msamples/s at 8 / 16 / 32 / 64 / 128 / 256 M samples per batch (C2: 3184 / 3227 / 3237 / 3260 / 3284 / 3297) */
     const uint64_t perSample = std::max<uint64_t>(1, std::max(pathMode ? 1u : rp->bsdf_samples, pathMode ? 1u : rp->light_samples));
-    uint64_t batch = ctx->cfg.max_samples_in_flight ? ctx->cfg.max_samples_in_flight : std::max<uint64_t>(1ull << 20, (1ull << 24) / perSample);
+    uint64_t batch = ctx->cfg.max_samples_in_flight ? ctx->cfg.max_samples_in_flight : std::max<uint64_t>(1ull << 20, (1ull << 26) / perSample);
     batch = std::max<uint64_t>(256, (batch + 255) / 256 * 256);
     batch = std::min<uint64_t>(batch, 1ull << 28);
     batch = std::min<uint64_t>(batch, std::max<uint64_t>(256, (total + 255) / 256 * 256));
