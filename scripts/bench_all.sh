@@ -1,7 +1,13 @@
 #!/bin/bash
-# One line per BASELINE config on one GPU (final numbers for BASELINE.md section 6)
+# One line per BASELINE config on one GPU (numbers for BASELINE.md / DESIGN.md); C5 = C4 at 4096 spp, here on ONE GPU.
+mkdir -p gpurun_out
 for wl in c1 c2 c3 c4; do
-  timeout -k 10 500 python -u bench.py --workload $wl --steps 2 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys; j=json.loads(sys.stdin.read()); r=j['roofline']
-print('$wl', j['value'], j['mrays_per_s'], r['achieved'], r['frac'], j['ms_per_step'], r['stage_ms_per_step'])" || exit 1
+  timeout -k 10 500 python3 -u bench.py --workload $wl --steps 3 --warmup 2 --no-cpu-baseline --no-extra-passes --no-secondary > gpurun_out/all_$wl.json 2> gpurun_out/all_$wl.err || { echo "$wl failed"; tail -3 gpurun_out/all_$wl.err; exit 1; }
+  python3 -c "
+import json; j=json.loads(open('gpurun_out/all_$wl.json').read().strip().splitlines()[-1])
+print('$wl', j['config']['workload'], j['value'], 'Msamples/s', j['mrays_per_s'], 'Mrays/s', j['ms_per_step'], 'ms', 'upload', j['config']['scene_upload_s'])"
 done
+timeout -k 10 500 python3 -u bench.py --workload c4 --spp 4096 --steps 1 --warmup 0 --no-cpu-baseline --no-extra-passes --no-secondary > gpurun_out/all_c5.json 2> gpurun_out/all_c5.err || { echo "c5 failed"; tail -3 gpurun_out/all_c5.err; exit 1; }
+python3 -c "
+import json; j=json.loads(open('gpurun_out/all_c5.json').read().strip().splitlines()[-1])
+print('c5 (one GPU)', j['value'], 'Msamples/s', j['mrays_per_s'], 'Mrays/s', j['ms_per_step'], 'ms')"
