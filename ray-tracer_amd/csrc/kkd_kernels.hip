@@ -376,7 +376,8 @@ __global__ void __launch_bounds__(KKD_SHADE_BLOCK, KKD_SHADE_WAVES * 256 / KKD_S
         const f2 u = nB > 1u ? draw2DArray(bp, s, flatB, (stock && nL > 1u) ? 1u : 0u, nB, b, LD)
                              : draw2D(bp, s, flatB, 1u + ((stock && nL == 1u) ? 1u : 0u), LD);
         f3 woLocal; float bsdfPdf; uint32_t sampledType;
-        const f3 bsdfVal = sampleBsdf(sc, its.material, its.wi, u, woLocal, bsdfPdf, sampledType);
+        woLocal = f3(0.f); bsdfPdf = 0.f; sampledType = 0u;
+        const f3 bsdfVal = ablation(bp, 8u) ? f3(0.f) : sampleBsdf(sc, its.material, its.wi, u, woLocal, bsdfPdf, sampledType);   /* ($KKD_DEBUG bit 8, ablation build: no BSDF sampling) */
         DRay r; killRay(r);
         float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!isZero(bsdfVal) && !dead) {
@@ -397,7 +398,7 @@ __global__ void __launch_bounds__(KKD_SHADE_BLOCK, KKD_SHADE_WAVES * 256 / KKD_S
     for (uint32_t l = 0; l < nL; ++l) {
         DRay r; killRay(r);
         float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((stock ? (btype & ESmooth) != 0u && !dead : btype != 0u) && sc.nEmitters) {      /* :140; direct.cpp:215 */
+        if ((stock ? (btype & ESmooth) != 0u && !dead : btype != 0u) && sc.nEmitters && !ablation(bp, 16u)) {      /* :140; direct.cpp:215 ($KKD_DEBUG bit 16, ablation build: no emitter sampling) */
             const uint32_t flatL = 2u + 2u * l + (stock ? 0u : 2u * nB);
             const f2 u = nL > 1u ? draw2DArray(bp, s, flatL, (!stock && nB > 1u) ? 1u : 0u, nL, l, LD)
                                  : draw2D(bp, s, flatL, 1u + ((!stock && nB == 1u) ? 1u : 0u), LD);
