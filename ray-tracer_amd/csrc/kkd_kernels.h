@@ -35,7 +35,7 @@ struct BatchParams {
      * (nTilesMine entries, device memory); nullptr = all tiles, tile id = running index.  The host deals the tiles out
      * round-robin along the Morton curve of the tile grid, so every rank's tiles are spread over the whole image. */
     const uint32_t *tileList;
-    uint32_t debug;                  /* developer ablation bits from $KKD_DEBUG: 1 = no film atomics, 2 = no BSDF-hit evaluation, 4 = no block-level film reduction, 8 = no BSDF sampling, 16 = no emitter sampling, 64 = per-lane primary walk */
+    uint32_t debug;                  /* developer ablation bits from $KKD_DEBUG: 1 = no film atomics, 2 = no BSDF-hit evaluation, 4 = no block-level film reduction, 8 = no BSDF sampling, 16 = no emitter sampling, 32 = no BSDF eval / pdf of the emitter sample, 64 = per-lane primary walk, 128 = fixed direction instead of the emitter sample */
 };
 
 /* SoA work buffers of one batch (all device memory). */

@@ -403,13 +403,17 @@ __global__ void __launch_bounds__(KKD_SHADE_BLOCK, KKD_SHADE_WAVES * 256 / KKD_S
             const f2 u = nL > 1u ? draw2DArray(bp, s, flatL, (!stock && nB > 1u) ? 1u : 0u, nL, l, LD)
                                  : draw2D(bp, s, flatL, 1u + ((!stock && nB == 1u) ? 1u : 0u), LD);
             DirectRec dRec; dRec.ref = its.p; dRec.refN = refN; dRec.emitter = -1;
-            const f3 value = sampleEmitterDirectUnoccluded(sc, dRec, u);
+            f3 value;
+            if (ablation(bp, 128u)) {     /* ($KKD_DEBUG bit 128, ablation build: a fixed direction instead of the emitter sample) */
+                dRec.d = normalize(f3(0.3f + u.x * 0.01f, 0.9f, 0.2f + u.y * 0.01f)); dRec.dist = 100.f; dRec.pdf = 1.f; dRec.measure = 0; dRec.emitter = 0;
+                dRec.p = dRec.ref + dRec.d * 100.f; dRec.n = -dRec.d; value = f3(1.f);
+            } else value = sampleEmitterDirectUnoccluded(sc, dRec, u);
             if (!isZero(value)) {
                 const f3 woLocal = its.sh.toLocal(dRec.d);
-                const f3 bsdfVal = evalBsdf(sc, its.material, its.wi, woLocal);
+                const f3 bsdfVal = ablation(bp, 32u) ? f3(0.5f) : evalBsdf(sc, its.material, its.wi, woLocal);   /* ($KKD_DEBUG bit 32: no BSDF eval / pdf for the emitter sample) */
                 if (!isZero(bsdfVal) && (!geoTest || dot(its.geoN, dRec.d) * woLocal.z > 0.f)) {   /* :154; direct.cpp:233-234 */
                     const bool onSurface = sc.emitters[dRec.emitter].type != KKD_EMITTER_POINT;
-                    const float bsdfPdf = onSurface ? pdfBsdf(sc, its.material, its.wi, woLocal) : 0.f;
+                    const float bsdfPdf = onSurface ? (ablation(bp, 32u) ? 0.5f : pdfBsdf(sc, its.material, its.wi, woLocal)) : 0.f;
                     const float pa = cL * dRec.pdf, pb = cB * bsdfPdf;
                     const float weight = stock ? fdiv(pa * pa, pa * pa + pb * pb) : fdiv(pa, pb + pa);   /* direct.cpp:241-243, 313-316 */
                     const f3 contrib = value * bsdfVal * (weight * invNL);
