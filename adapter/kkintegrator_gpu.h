@@ -191,8 +191,10 @@ static bool kkdRenderOnGpu(Scene *scene, RenderQueue *queue, const RenderJob *jo
         rp.bsdf_samples = (uint32_t) bsdfSamples; rp.light_samples = (uint32_t) lightSamples; rp.hide_emitters = hideEmittersFlag ? 1 : 0;
         rp.block_size = scene->getBlockSize(); rp.tile_count = 1;
         /* the scene's sampler plugin: Mitsuba's default ldsampler (src/samplers/ldsampler.cpp; its 'dimension' is not readable
-         * from outside the plugin: the default, 4) or the independent sampler; other samplers fall back to independent */
+         * from outside the plugin: the default, 4), the stratified sampler (src/samplers/stratified.cpp; its getSampleCount()
+         * is already the perfect square) or the independent sampler; other samplers fall back to independent */
         if (scene->getSampler()->getClass()->getName() == "LowDiscrepancySampler") rp.sampler = KKD_SAMPLER_LDSAMPLER;
+        else if (scene->getSampler()->getClass()->getName() == "StratifiedSampler") rp.sampler = KKD_SAMPLER_STRATIFIED;
         else if (scene->getSampler()->getClass()->getName() != "IndependentSampler")
             SLog(EWarn, "kkIntegrator: sampler \"%s\" is not available on the GPU path, using independent samples", scene->getSampler()->getClass()->getName().c_str());
         ref<ImageBlock> block = new ImageBlock(Bitmap::ESpectrumAlphaWeight, film->getCropSize(), NULL);

@@ -217,9 +217,14 @@ typedef struct kkd_render_params {
     /* which Sampler: KKD_SAMPLER_INDEPENDENT = samplers/independent.cpp:82-103 (every dimension a fresh uniform number);
      * KKD_SAMPLER_LDSAMPLER = samplers/ldsampler.cpp:148-229, Mitsuba's default: per pixel, each of the first
      * sampler_dimension 1D / 2D requests and every requested sample array (kk/direct.cpp:44-47: bsdfSamples / lightSamples > 1)
-     * is one (0,2)-sequence over the pixel's samples, randomly scrambled and shuffled; later requests are independent. */
+     * is one (0,2)-sequence over the pixel's samples, randomly scrambled and shuffled; later requests are independent;
+     * KKD_SAMPLER_STRATIFIED = samplers/stratified.cpp:147-207: each of the first sampler_dimension 2D (1D) requests visits the
+     * res x res cells (res^2 intervals) once over the pixel's samples in a shuffled order, jittered inside the cell; requested
+     * arrays are Latin hypercubes (libcore/util.cpp:565-576).  res^2 = the sample count rounded up to a perfect square
+     * (stratified.cpp:62-79 renders that many; this library renders the spp it is given and leaves the last strata empty, so
+     * callers pass a perfect square, as the Python mirror and the Mitsuba adapter do). */
     uint32_t sampler;
-    uint32_t sampler_dimension;   /* ldsampler 'dimension' (0 = its default 4) */
+    uint32_t sampler_dimension;   /* ldsampler / stratified 'dimension' (0 = their default 4) */
     /* Sampler::getSampleCount() of the whole render when this call renders only the share [sample_first, sample_first + spp) of
      * every pixel's samples (sample-split mode); 0 = spp.  Sets the size of the ldsampler's point sets (rounded up to a power of
      * two, ldsampler.cpp:83-87) and the scale of the ray differentials (integrator.cpp:144-145). */
@@ -228,6 +233,7 @@ typedef struct kkd_render_params {
 } kkd_render_params;
 #define KKD_SAMPLER_INDEPENDENT 0u
 #define KKD_SAMPLER_LDSAMPLER   1u
+#define KKD_SAMPLER_STRATIFIED  2u
 #define KKD_INTEGRATOR_KK     0u
 #define KKD_INTEGRATOR_DIRECT 1u
 #define KKD_INTEGRATOR_PATH   2u
@@ -347,6 +353,10 @@ int kkd_probe_rfilter(int rfilter_type, float radius, const float *param2, float
  * for one stream -- kind 0: 2D request `index` (out: count x 2), kind 1: 1D request `index` (out: count), kind 2: requested
  * array `index` with `array_n` entries per sample (out: count x array_n x 2) -- when the point sets hold set_size samples. */
 int kkd_probe_ldsampler(uint64_t seed, uint32_t pixel, int kind, uint32_t index, uint32_t array_n, uint32_t set_size, uint32_t count, float *out);
+/* The same for KKD_SAMPLER_STRATIFIED (StratifiedSampler::next2D / next1D, stratified.cpp:181-207, and the Latin hypercube
+ * arrays of generate(), :158-162) with `resolution`^2 samples per pixel; flat_dim (even) = the dimension of the independent
+ * stream whose values jitter the request inside its cell, as in a render. */
+int kkd_probe_stratified(uint64_t seed, uint32_t pixel, int kind, uint32_t index, uint32_t array_n, uint32_t resolution, uint32_t flat_dim, uint32_t count, float *out);
 
 /* ---- film develop and output: the step right after the path ---- */
 

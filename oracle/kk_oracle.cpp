@@ -119,6 +119,17 @@ void ora_ldsampler(uint64_t seed, uint32_t pixel, int kind, uint32_t index, uint
         else for (uint32_t e = 0; e < arrayN; ++e) { V2 v = s.next2DArray(index, arrayN, e); out[2 * ((size_t)j * arrayN + e)] = v.x; out[2 * ((size_t)j * arrayN + e) + 1] = v.y; }
     }
 }
+/* the same for the stratified sampler; flatDim = dimension of the independent stream that supplies the offsets inside the cells */
+void ora_stratified(uint64_t seed, uint32_t pixel, int kind, uint32_t index, uint32_t arrayN, uint32_t res, uint32_t flatDim, uint32_t count, float *out) {
+    for (uint32_t j = 0; j < count; ++j) {
+        SampleStream s(seed, pixel, j);
+        s.useStratified(res, 0xFFFFFFFFu);
+        s.dim = flatDim;
+        if (kind == 0) { s.dim2D = index; V2 v = s.next2D(); out[2 * j] = v.x; out[2 * j + 1] = v.y; }
+        else if (kind == 1) { s.dim1D = index; out[j] = s.next1D(); }
+        else for (uint32_t e = 0; e < arrayN; ++e) { V2 v = s.next2DArray(index, arrayN, e); out[2 * ((size_t)j * arrayN + e)] = v.x; out[2 * ((size_t)j * arrayN + e) + 1] = v.y; }
+    }
+}
 void ora_clip_aabb(const float *tri9, const float *box6, float *out6) {
     AABB b(V3(box6[0], box6[1], box6[2]), V3(box6[3], box6[4], box6[5]));
     AABB r = triClippedAABB(V3(tri9[0], tri9[1], tri9[2]), V3(tri9[3], tri9[4], tri9[5]), V3(tri9[6], tri9[7], tri9[8]), b);

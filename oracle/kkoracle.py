@@ -42,6 +42,8 @@ def lib():
         L.ora_sample_stream.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, abi.pf32]
         L.ora_ldsampler.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, abi.pf32]
         L.ora_ldsampler.restype = None
+        L.ora_stratified.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, abi.pf32]
+        L.ora_stratified.restype = None
         L.ora_clip_aabb.argtypes = [abi.pf32, abi.pf32, abi.pf32]
         L.ora_bsdf_eval.argtypes = [C.c_void_p, C.c_int, abi.pf32, abi.pf32, abi.pf32, abi.pf32]
         L.ora_bsdf_sample.argtypes = [C.c_void_p, C.c_int, abi.pf32, abi.pf32, C.c_uint64, abi.pf32]
@@ -182,6 +184,13 @@ def ldsampler(seed, pixel, kind, index, array_n, set_size, count):
     """values of samples 0 ... count-1: kind 0 -> (count, 2), 1 -> (count,), 2 -> (count, array_n, 2)"""
     out = np.zeros(count * (1 if kind == 1 else 2 * (array_n if kind == 2 else 1)), np.float32)
     lib().ora_ldsampler(seed, pixel, kind, index, array_n, set_size, count, _fp(out))
+    return out if kind == 1 else out.reshape((count, 2) if kind == 0 else (count, array_n, 2))
+
+
+def stratified(seed, pixel, kind, index, array_n, res, flat_dim, count):
+    """stratified sampler, shapes as ldsampler(); flat_dim: dimension of the independent stream that jitters the request"""
+    out = np.zeros(count * (1 if kind == 1 else 2 * (array_n if kind == 2 else 1)), np.float32)
+    lib().ora_stratified(seed, pixel, kind, index, array_n, res, flat_dim, count, _fp(out))
     return out if kind == 1 else out.reshape((count, 2) if kind == 0 else (count, array_n, 2))
 
 

@@ -293,9 +293,16 @@ struct SampleStream {
     uint32_t dim;
     uint32_t cache[4]; int cachedBlock;
     uint32_t ldSet = 0, ldDim = 0, dim2D = 0, dim1D = 0;       /* ldSet = 0: independent */
+    uint32_t stratRes = 0;                                     /* > 0: stratified with stratRes^2 samples per pixel (ldSet = stratRes^2) */
     SampleStream(uint64_t seed, uint32_t pix, uint32_t smp)
         : pixel(pix), sample(smp), seedLo((uint32_t)seed), seedHi((uint32_t)(seed >> 32)), dim(0), cachedBlock(-1) {}
     void useLdSampler(uint32_t setSize, uint32_t dimension) { ldSet = setSize; ldDim = dimension; }
+    /* samplers/stratified.cpp:147-207: request k < dimension visits cell perm_k[sample] of the res x res grid (res^2 intervals),
+     * offset inside the cell by the values of the independent stream at the request's dimensions; arrays are Latin hypercubes
+     * over all res^2 * n entries (libcore/util.cpp:565-576).  Shuffles: hash permutations as for the ldsampler.  Results are
+     * capped below one (the reference's (k + xi) * (1 / res) can round to one in single precision). */
+    void useStratified(uint32_t res, uint32_t dimension) { stratRes = res; ldSet = res * res; ldDim = dimension; }
+    static Float belowOne(Float v) { return v < 0x1.fffffep-1f ? v : 0x1.fffffep-1f; }
     Float independent1D() {
         int block = (int)(dim >> 2);
         if (block != cachedBlock) {
@@ -311,7 +318,12 @@ struct SampleStream {
     }
     Float next1D() {
         const uint32_t req = dim1D++;
-        if (ldSet && req < ldDim) {
+        if (stratRes && req < ldDim) {
+            const Float xi = independent1D();
+            uint32_t r[4]; streamWords(2 * req + 1, r);
+            return belowOne(((Float)permuteIndex(sample % ldSet, ldSet, r[2]) + xi) * (1.0f / (Float)ldSet));
+        }
+        if (ldSet && !stratRes && req < ldDim) {
             dim += 1;
             uint32_t r[4]; streamWords(2 * req + 1, r);
             return radicalInverse2Single(permuteIndex(sample % ldSet, ldSet, r[2]), r[0]);
@@ -320,7 +332,14 @@ struct SampleStream {
     }
     V2 next2D() {
         const uint32_t req = dim2D++;
-        if (ldSet && req < ldDim) {
+        if (stratRes && req < ldDim) {
+            const Float xa = independent1D(), xb = independent1D();
+            uint32_t r[4]; streamWords(2 * req, r);
+            const uint32_t k = permuteIndex(sample % ldSet, ldSet, r[2]), x = k % stratRes, y = k / stratRes;
+            const Float inv = 1.0f / (Float)stratRes;
+            return V2{ belowOne(((Float)x + xa) * inv), belowOne(((Float)y + xb) * inv) };
+        }
+        if (ldSet && !stratRes && req < ldDim) {
             dim += 2;
             uint32_t r[4]; streamWords(2 * req, r);
             const uint32_t j = permuteIndex(sample % ldSet, ldSet, r[2]);
@@ -330,6 +349,13 @@ struct SampleStream {
     }
     /* element e of this sample's n-element slice of requested array `array` (Sampler::next2DArray, sampler.cpp:79-90) */
     V2 next2DArray(uint32_t array, uint32_t n, uint32_t e) {
+        if (stratRes) {
+            const Float xa = independent1D(), xb = independent1D();
+            uint32_t r[4]; streamWords(0x10000u + array, r);
+            const uint32_t size = ldSet * n, q = (sample * n + e) % size;
+            const Float delta = 1.0f / (Float)size;
+            return V2{ belowOne(((Float)permuteIndex(q, size, r[2]) + xa) * delta), belowOne(((Float)permuteIndex(q, size, r[3]) + xb) * delta) };
+        }
         if (ldSet) {
             dim += 2;
             uint32_t r[4]; streamWords(0x10000u + array, r);

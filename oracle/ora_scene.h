@@ -516,6 +516,10 @@ struct RenderParams { uint32_t spp, nB, nL; bool hideEmitters; uint32_t blockSiz
                       static uint32_t pow2ceil(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
                       void configure(SampleStream &rng) const {                                                  /* ldsampler.cpp:76-87 */
                           if (sampler == KKD_SAMPLER_LDSAMPLER) rng.useLdSampler(pow2ceil(total()), samplerDimension ? samplerDimension : 4u);
+                          if (sampler == KKD_SAMPLER_STRATIFIED) {                                               /* stratified.cpp:62-79 */
+                              uint32_t res = 1; while ((uint64_t)res * res < total()) ++res;
+                              rng.useStratified(res, samplerDimension ? samplerDimension : 4u);
+                          }
                       } };
 struct Stats { std::atomic<uint64_t> samples{0}, raysClosest{0}, raysShadow{0}, nodes{0}, tris{0}; };
 

@@ -164,6 +164,21 @@ int kkd_probe_ldsampler(uint64_t seed, uint32_t pixel, int kind, uint32_t index,
     return KKD_OK;
 }
 
+int kkd_probe_stratified(uint64_t seed, uint32_t pixel, int kind, uint32_t index, uint32_t array_n, uint32_t resolution, uint32_t flat_dim, uint32_t count, float *out) {
+    if (!out || !resolution || resolution > 4096u || (flat_dim & 1u) || kind < 0 || kind > 2 || (kind == 2 && !array_n)) return KKD_ERR_INVALID;
+    const uint32_t set = resolution * resolution;
+    for (uint32_t j = 0; j < count; ++j) {
+        const f2 jit = sample2D(seed, pixel, j, flat_dim);
+        if (kind == 0) { const f2 v = stratSample2D(seed, pixel, 2u * index, j, resolution, jit); out[2 * j] = v.x; out[2 * j + 1] = v.y; }
+        else if (kind == 1) out[j] = stratSample1D(seed, pixel, 2u * index + 1u, j, resolution, jit.x);
+        else for (uint32_t e = 0; e < array_n; ++e) {
+            const f2 v = latinHypercube2D(seed, pixel, 0x10000u + index, j * array_n + e, set * array_n, sample2D(seed, pixel, j, flat_dim + 2u * e));
+            out[2 * ((size_t)j * array_n + e)] = v.x; out[2 * ((size_t)j * array_n + e) + 1] = v.y;
+        }
+    }
+    return KKD_OK;
+}
+
 int kkd_probe_rfilter(int rfilter_type, float radius, const float *param2, float *values32, float *scale_factor, int *border) {
     if (!param2 || !values32 || !scale_factor || !border || rfilter_type < 0 || rfilter_type > KKD_RFILTER_LANCZOS || !(radius > 0.f)) return KKD_ERR_INVALID;
     DFilter f;
@@ -486,11 +501,11 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     if (rp->spp == 0) return fail(ctx, KKD_ERR_INVALID, "spp must be positive");
     /* kk/direct.cpp:165-166 divides by both counts: zero is not a meaningful configuration */
     if (rp->integrator > KKD_INTEGRATOR_PATH) return fail(ctx, KKD_ERR_INVALID, "unknown integrator");
-    if (rp->sampler > KKD_SAMPLER_LDSAMPLER) return fail(ctx, KKD_ERR_INVALID, "unknown sampler");
+    if (rp->sampler > KKD_SAMPLER_STRATIFIED) return fail(ctx, KKD_ERR_INVALID, "unknown sampler");
     if (rp->sample_count_total && (uint64_t)rp->sample_first + rp->spp > rp->sample_count_total)
         return fail(ctx, KKD_ERR_INVALID, "sample_first + spp exceeds sample_count_total");
-    if (rp->sampler == KKD_SAMPLER_LDSAMPLER && (uint64_t)(rp->sample_count_total ? rp->sample_count_total : rp->spp) * 64u > 0x40000000ull)
-        return fail(ctx, KKD_ERR_UNSUPPORTED, "ldsampler: more than 2^24 samples per pixel");
+    if (rp->sampler != KKD_SAMPLER_INDEPENDENT && (uint64_t)(rp->sample_count_total ? rp->sample_count_total : rp->spp) * 64u > 0x40000000ull)
+        return fail(ctx, KKD_ERR_UNSUPPORTED, "ldsampler / stratified: more than 2^24 samples per pixel");
     const bool pathMode = rp->integrator == KKD_INTEGRATOR_PATH;
     /* MonteCarloIntegrator (librender/integrator.cpp:190-233): maxDepth = -1 or > 0, rrDepth > 0 */
     if (pathMode && (rp->max_depth == 0 || rp->max_depth < -1)) return fail(ctx, KKD_ERR_INVALID, "maxDepth must be -1 (unbounded) or positive");
@@ -612,6 +627,10 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     bp.diffScale = 1.0f / std::sqrt((float)sampleCountTotal);
     bp.sampler = rp->sampler; bp.samplerDim = rp->sampler_dimension ? rp->sampler_dimension : 4u;   /* ldsampler.cpp:81 */
     bp.samplerSet = pow2ceil(sampleCountTotal);                                                      /* ldsampler.cpp:83-87 */
+    if (rp->sampler == KKD_SAMPLER_STRATIFIED) {                                                     /* stratified.cpp:62-79 */
+        uint32_t res = 1; while ((uint64_t)res * res < sampleCountTotal) ++res;
+        bp.samplerRes = res; bp.samplerSet = res * res;
+    }
     bp.integrator = rp->integrator; bp.strictNormals = rp->strict_normals != 0;
     bp.maxDepth = rp->max_depth; bp.rrDepth = rp->rr_depth; bp.depth = 1;
     bp.chunksShift = 32; bp.pixShift = 32;

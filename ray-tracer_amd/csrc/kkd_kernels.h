@@ -23,7 +23,8 @@ struct BatchParams {
      * group(w0) = (tile0 * bs^2 + pin0) * chunks + chunk0 */
     uint32_t chunk0, pin0, tile0, chunksShift /* log2(chunks) or 32 */, pixShift /* log2(bs^2) or 32 */;
     uint32_t nB, nL, hideEmitters;
-    uint32_t sampler, samplerDim, samplerSet;   /* KKD_SAMPLER_*; ldsampler: 'dimension', size of the per-pixel point sets (a power of two) */
+    uint32_t sampler, samplerDim, samplerSet;   /* KKD_SAMPLER_*; 'dimension'; size of the per-pixel point sets (ldsampler: a power of two, stratified: samplerRes^2) */
+    uint32_t samplerRes;             /* stratified: cells per side (stratified.cpp:64-74) */
     float diffScale;                 /* 1 / sqrt(spp): RayDifferential::scaleDifferential of the camera ray (integrator.cpp:144-145, 181) */
     uint32_t integrator, strictNormals;   /* KKD_INTEGRATOR_*; 'strictNormals' of the stock direct / path plugins */
     int32_t maxDepth, rrDepth;            /* path plugin: 'maxDepth', 'rrDepth' */

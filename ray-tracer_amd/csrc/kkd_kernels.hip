@@ -67,24 +67,30 @@ __device__ __forceinline__ SampleId mapWorkItem(const BatchParams &bp, uint32_t 
 }
 
 /* Sampler::next2D / next2DArray / next1D of sample s: `flat` is the dimension of the independent stream (what every request
- * beyond the ldsampler's 'dimension' falls back to, ldsampler.cpp:214-228), `req` the running number of the 2D (1D) request
- * within the sample, (array, n, e) element e of the sample's n-element slice of requested array `array`.  ld: the ldsampler is
- * in use -- a compile-time constant in kShade, whose register budget has no room for both samplers. */
-__device__ __forceinline__ f2 draw2D(const BatchParams &bp, const SampleId &s, uint32_t flat, uint32_t req, bool ld) {
-    if (ld && req < bp.samplerDim) return ldSample2D(bp.seed, s.pixel, 2u * req, s.sample, bp.samplerSet);
-    return sample2D(bp.seed, s.pixel, s.sample, flat);
+ * beyond the sampler's 'dimension' falls back to, ldsampler.cpp:214-228, stratified.cpp:186-187, 201-205), `req` the running
+ * number of the 2D (1D) request within the sample, (array, n, e) element e of the sample's n-element slice of requested array
+ * `array`.  mode: KKD_SAMPLER_* -- a compile-time constant in kShade, whose register budget has no room for all samplers. */
+__device__ __forceinline__ f2 draw2D(const BatchParams &bp, const SampleId &s, uint32_t flat, uint32_t req, uint32_t mode) {
+    if (mode == KKD_SAMPLER_LDSAMPLER && req < bp.samplerDim) return ldSample2D(bp.seed, s.pixel, 2u * req, s.sample, bp.samplerSet);
+    const f2 u = sample2D(bp.seed, s.pixel, s.sample, flat);
+    if (mode == KKD_SAMPLER_STRATIFIED && req < bp.samplerDim) return stratSample2D(bp.seed, s.pixel, 2u * req, s.sample, bp.samplerRes, u);
+    return u;
 }
-__device__ __forceinline__ f2 draw2DArray(const BatchParams &bp, const SampleId &s, uint32_t flat, uint32_t array, uint32_t n, uint32_t e, bool ld) {
-    if (ld) return ldSample2D(bp.seed, s.pixel, 0x10000u + array, s.sample * n + e, bp.samplerSet * n);
-    return sample2D(bp.seed, s.pixel, s.sample, flat);
+__device__ __forceinline__ f2 draw2DArray(const BatchParams &bp, const SampleId &s, uint32_t flat, uint32_t array, uint32_t n, uint32_t e, uint32_t mode) {
+    if (mode == KKD_SAMPLER_LDSAMPLER) return ldSample2D(bp.seed, s.pixel, 0x10000u + array, s.sample * n + e, bp.samplerSet * n);
+    const f2 u = sample2D(bp.seed, s.pixel, s.sample, flat);
+    if (mode == KKD_SAMPLER_STRATIFIED) return latinHypercube2D(bp.seed, s.pixel, 0x10000u + array, s.sample * n + e, bp.samplerSet * n, u);
+    return u;
 }
-__device__ __forceinline__ float draw1D(const BatchParams &bp, const SampleId &s, uint32_t flat, uint32_t req, bool ld) {
-    if (ld && req < bp.samplerDim) return ldSample1D(bp.seed, s.pixel, 2u * req + 1u, s.sample, bp.samplerSet);
-    return sample2D(bp.seed, s.pixel, s.sample, flat).x;
+__device__ __forceinline__ float draw1D(const BatchParams &bp, const SampleId &s, uint32_t flat, uint32_t req, uint32_t mode) {
+    if (mode == KKD_SAMPLER_LDSAMPLER && req < bp.samplerDim) return ldSample1D(bp.seed, s.pixel, 2u * req + 1u, s.sample, bp.samplerSet);
+    const float u = sample2D(bp.seed, s.pixel, s.sample, flat).x;
+    if (mode == KKD_SAMPLER_STRATIFIED && req < bp.samplerDim) return stratSample1D(bp.seed, s.pixel, 2u * req + 1u, s.sample, bp.samplerRes, u);
+    return u;
 }
 
-__device__ __forceinline__ DRay primaryRay(const DScene &sc, const BatchParams &bp, const SampleId &s, float &sx, float &sy, bool ld) {
-    const f2 jit = draw2D(bp, s, 0u, 0u, ld);
+__device__ __forceinline__ DRay primaryRay(const DScene &sc, const BatchParams &bp, const SampleId &s, float &sx, float &sy, uint32_t mode) {
+    const f2 jit = draw2D(bp, s, 0u, 0u, mode);
     sx = (float)s.X + jit.x; sy = (float)s.Y + jit.y;      /* integrator.cpp:171 */
     return sensorRay(sc.sensor, sx, sy);
 }
@@ -120,7 +126,7 @@ __global__ void __launch_bounds__(BLOCK, !PACKET || KKD_PRIMARY_RAYS == 1 ? 8 : 
         ray[r].maxt = -1.f; ray[r].mint = 0.f; ray[r].ox = ray[r].oy = ray[r].oz = 0.f; ray[r].dx = ray[r].dy = 0.f; ray[r].dz = 1.f;
         float sx, sy;
         active[r] = s.active;
-        if (s.active) ray[r] = primaryRay(sc, bp, s, sx, sy, bp.sampler == KKD_SAMPLER_LDSAMPLER);
+        if (s.active) ray[r] = primaryRay(sc, bp, s, sx, sy, bp.sampler);
     }
     const void *triTable = PROJ ? (const void *)sc.projTris : (const void *)sc.tris;
     if (PACKET) traversePacket<COUNT, PROJ, R>(sc.wideNodes, triTable, ray, sstack + (threadIdx.x >> 6) * kMaxTraversalStack, h, nn, nt);
@@ -302,7 +308,7 @@ __global__ void __launch_bounds__(256) kEnvMiss(DScene sc, BatchParams bp, WaveB
     const SampleId s = mapWorkItem(bp, i);
     if (!s.active) return;
     float sx, sy;
-    const DRay ray = primaryRay(sc, bp, s, sx, sy, bp.sampler == KKD_SAMPLER_LDSAMPLER);
+    const DRay ray = primaryRay(sc, bp, s, sx, sy, bp.sampler);
     const f3 d(ray.dx, ray.dy, ray.dz); f3 rxD, ryD;
     sensorDifferentials(sc.sensor, sx, sy, bp.diffScale, d, rxD, ryD);
     const f3 e = envEvalFiltered(sc.env, d, rxD, ryD);
@@ -325,7 +331,7 @@ __device__ __forceinline__ void storeRay(DRay *dst, const DRay &r) {
                                   64-spp C4 frame, but kResolve is starved instead, 120 instead of 42 ms: the frame time does not move, 198.0 vs
                                   197.6 ms -- the pipeline as a whole is bound by VALU issue, lanes only redistribute it) */
 #endif
-template <bool LD>      /* the ldsampler is in use */
+template <uint32_t LD>  /* KKD_SAMPLER_* in use */
 __global__ void __launch_bounds__(KKD_SHADE_BLOCK, KKD_SHADE_WAVES * 256 / KKD_SHADE_BLOCK) kShade(DScene sc, BatchParams bp, WaveBuffers wb) {
     const uint32_t i = blockIdx.x * KKD_SHADE_BLOCK + threadIdx.x;
     if (i >= bp.count) return;
@@ -496,7 +502,7 @@ __global__ void __launch_bounds__(256, 4) kPathBounce(DScene sc, BatchParams bp,
             if (pl.terminate) cont = false;
             if (cont && (int)bp.depth - 1 >= bp.rrDepth) {                               /* :276-286, depth before the increment */
                 const float q = fminf(maxComp(T) * eta * eta, 0.95f);
-                const float u = draw1D(bp, s, 2u + 6u * (bp.depth - 2u) + 4u, bp.depth - 1u - (uint32_t)bp.rrDepth, bp.sampler == KKD_SAMPLER_LDSAMPLER);   /* the roulette is the path's only 1D request */
+                const float u = draw1D(bp, s, 2u + 6u * (bp.depth - 2u) + 4u, bp.depth - 1u - (uint32_t)bp.rrDepth, bp.sampler);   /* the roulette is the path's only 1D request */
                 if (u >= q) cont = false; else T = T / q;
             }
             if (cont && ((bp.maxDepth > 0 && (int)bp.depth >= bp.maxDepth) || (bp.strictNormals && dot(rd, its.geoN) * its.wi.z >= 0.f))) cont = false;   /* :156-165 */
@@ -506,7 +512,7 @@ __global__ void __launch_bounds__(256, 4) kPathBounce(DScene sc, BatchParams bp,
                 const f3 refN = (btype & (ETransmission | EBackSide)) ? f3(0.f) : its.sh.n;
                 nrefN = make_float4(refN.x, refN.y, refN.z, eta);
                 if ((btype & ESmooth) != 0u && sc.nEmitters) {                           /* :172-200 */
-                    const f2 u = draw2D(bp, s, dim0, 1u + 2u * (bp.depth - 1u), bp.sampler == KKD_SAMPLER_LDSAMPLER);
+                    const f2 u = draw2D(bp, s, dim0, 1u + 2u * (bp.depth - 1u), bp.sampler);
                     DirectRec lRec; lRec.ref = its.p; lRec.refN = refN; lRec.emitter = -1;
                     const f3 lval = sampleEmitterDirectUnoccluded(sc, lRec, u);
                     if (!isZero(lval)) {
@@ -524,7 +530,7 @@ __global__ void __launch_bounds__(256, 4) kPathBounce(DScene sc, BatchParams bp,
                         }
                     }
                 }
-                const f2 u = draw2D(bp, s, dim0 + 2u, 2u + 2u * (bp.depth - 1u), bp.sampler == KKD_SAMPLER_LDSAMPLER);             /* :206-225 */
+                const f2 u = draw2D(bp, s, dim0 + 2u, 2u + 2u * (bp.depth - 1u), bp.sampler);             /* :206-225 */
                 f3 woLocal; float pdf; uint32_t sampledType;
                 const f3 bsdfWeight = sampleBsdf(sc, its.material, its.wi, u, woLocal, pdf, sampledType);
                 if (!isZero(bsdfWeight)) {
@@ -665,7 +671,7 @@ __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveB
     float val[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
     float sx = 0.f, sy = 0.f;
     if (s.active) {
-        const f2 jit = draw2D(bp, s, 0u, 0u, bp.sampler == KKD_SAMPLER_LDSAMPLER);
+        const f2 jit = draw2D(bp, s, 0u, 0u, bp.sampler);
         sx = (float)s.X + jit.x; sy = (float)s.Y + jit.y;
         const float4 acc = wb.accum[i];
         f3 L(acc.x, acc.y, acc.z);
@@ -910,8 +916,10 @@ void launchTracePhased(hipStream_t st, const DScene &sc, const DRay *rays, uint6
 }
 
 void launchShade(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb) {
-    if (bp.sampler == KKD_SAMPLER_LDSAMPLER) hipLaunchKernelGGL(kShade<true>, dim3(blocksFor(bp.count, KKD_SHADE_BLOCK)), dim3(KKD_SHADE_BLOCK), 0, st, sc, bp, wb);
-    else hipLaunchKernelGGL(kShade<false>, dim3(blocksFor(bp.count, KKD_SHADE_BLOCK)), dim3(KKD_SHADE_BLOCK), 0, st, sc, bp, wb);
+    const dim3 grid(blocksFor(bp.count, KKD_SHADE_BLOCK)), block(KKD_SHADE_BLOCK);
+    if (bp.sampler == KKD_SAMPLER_LDSAMPLER) hipLaunchKernelGGL(kShade<KKD_SAMPLER_LDSAMPLER>, grid, block, 0, st, sc, bp, wb);
+    else if (bp.sampler == KKD_SAMPLER_STRATIFIED) hipLaunchKernelGGL(kShade<KKD_SAMPLER_STRATIFIED>, grid, block, 0, st, sc, bp, wb);
+    else hipLaunchKernelGGL(kShade<KKD_SAMPLER_INDEPENDENT>, grid, block, 0, st, sc, bp, wb);
     if (!bp.hideEmitters && sc.envEmitter >= 0) hipLaunchKernelGGL(kEnvMiss, dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, wb);
 }
 

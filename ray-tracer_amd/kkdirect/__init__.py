@@ -410,6 +410,33 @@ class LowDiscrepancySampler:
         return dict(sampler=abi.SAMPLER_LDSAMPLER, sampler_dimension=self.dimension) if self.dimension else dict(sampler=abi.SAMPLER_INDEPENDENT)
 
 
+class StratifiedSampler:
+    """Host mirror of the 'stratified' plugin (reference src/samplers/stratified.cpp:60-91): sampleCount is rounded up to a
+    perfect square with a warning, 'dimension' stratified requests per sample (default 4)."""
+    PLUGIN_NAME = "stratified"
+
+    def __init__(self, props=None, **kw):
+        props = dict(props or {}, **kw)
+        desired = int(props.pop("sampleCount", 4))
+        self.dimension = int(props.pop("dimension", 4))
+        if props:
+            raise ValueError("stratified: unreferenced properties %s" % sorted(props))
+        if desired < 1 or self.dimension < 0:
+            raise ValueError("stratified: sampleCount must be positive, dimension non-negative")
+        res = 1
+        while res * res < desired:
+            res += 1
+        self.resolution, self.sampleCount = res, res * res
+        if self.sampleCount != desired:
+            import warnings
+            warnings.warn("Sample count should be a perfect square -- rounding to %d" % self.sampleCount)
+
+    def render_args(self):
+        # dimension 0 means "the default" at the C ABI; without stratified requests the sampler is passed as the independent one
+        # (the reference would still hand out Latin hypercube arrays for bsdfSamples / lightSamples > 1 then)
+        return dict(sampler=abi.SAMPLER_STRATIFIED, sampler_dimension=self.dimension) if self.dimension else dict(sampler=abi.SAMPLER_INDEPENDENT)
+
+
 class DirectIntegrator:
     """Host mirror of the reference's DirectIntegrator plugin (src/integrators/kk/direct.cpp:15-48).
 

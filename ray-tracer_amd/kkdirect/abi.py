@@ -93,7 +93,7 @@ class RenderParams(C.Structure):
 
 
 INTEGRATOR_KK, INTEGRATOR_DIRECT, INTEGRATOR_PATH = 0, 1, 2
-SAMPLER_INDEPENDENT, SAMPLER_LDSAMPLER = 0, 1
+SAMPLER_INDEPENDENT, SAMPLER_LDSAMPLER, SAMPLER_STRATIFIED = 0, 1, 2
 
 
 class Stats(C.Structure):
@@ -129,6 +129,7 @@ ENTRY_POINTS = {
     "kkd_accel_info": (C.c_int, [C.c_void_p, pu32, pu32, C.POINTER(u64), C.POINTER(u64)]),
     "kkd_probe_rough_transmittance": (C.c_int, [C.c_int, C.c_float, C.c_float, pf32, pf32]),
     "kkd_probe_ldsampler": (C.c_int, [u64, u32, C.c_int, u32, u32, u32, u32, pf32]),
+    "kkd_probe_stratified": (C.c_int, [u64, u32, C.c_int, u32, u32, u32, u32, u32, pf32]),
     "kkd_probe_rfilter": (C.c_int, [C.c_int, C.c_float, pf32, pf32, pf32, C.POINTER(C.c_int)]),
     "kkd_develop_device": (C.c_int, [C.c_void_p, C.c_void_p, u32, u32, i32, C.c_void_p]),
     "kkd_develop": (C.c_int, [C.c_void_p, pf32, u32, u32, i32, pf32]),
