@@ -410,6 +410,15 @@ int kkd_write_exr(const char *path, const float *pixels, uint32_t width, uint32_
  * cnpy::npy_save writes it.  Host only, no context needed. */
 int kkd_write_npy(const char *path, const float *pixels, uint32_t width, uint32_t height, uint32_t channels);
 
+/* MFilm::develop with fileFormat = matlab (MFilm's default) or mathematica (src/films/mfilm.cpp:269-334): a .m text file that
+ * assigns the image to `variable` (NULL = "data", mfilm.cpp:135), one matrix per channel, numbers printed with `digits`
+ * significant digits (0 = 4, mfilm.cpp:134) the way `ostream << float` with setprecision(digits) prints them; Mathematica
+ * numbers use "*^" for the exponent.  Same bytes as the reference's loop.  Host only, no context needed. */
+#define KKD_MFILM_MATLAB      0
+#define KKD_MFILM_MATHEMATICA 1
+int kkd_write_mfilm_text(const char *path, const float *pixels, uint32_t width, uint32_t height, uint32_t channels,
+                         int32_t file_format, int32_t digits, const char *variable);
+
 /* ---- parameter extraction for the Mitsuba-side adapter ---- */
 
 /* Decodes the byte stream InstanceManager::serialize(stream, bsdf) writes (src/libcore/serialization.cpp:73-87) for

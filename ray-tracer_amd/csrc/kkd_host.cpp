@@ -821,6 +821,50 @@ int kkd_write_npy(const char *path, const float *pixels, uint32_t width, uint32_
     return ok ? KKD_OK : KKD_ERR_INVALID;
 }
 
+/* MFilm::develop, matlab / mathematica branch (src/films/mfilm.cpp:269-334).  `os << float` under setprecision(d) with the
+ * default floatfield is printf's %.{d}g of the value (precision 0 is read as 1 by both). */
+int kkd_write_mfilm_text(const char *path, const float *pixels, uint32_t width, uint32_t height, uint32_t channels,
+                         int32_t file_format, int32_t digits, const char *variable) {
+    if (!path || channels == 0 || width == 0 || height == 0 || !pixels || digits < 0 || digits > 64
+        || (file_format != KKD_MFILM_MATLAB && file_format != KKD_MFILM_MATHEMATICA)) return KKD_ERR_INVALID;
+    FILE *f = std::fopen(path, "w");
+    if (!f) return KKD_ERR_INVALID;
+    const std::string var = variable ? variable : "data";
+    const int prec = digits ? digits : 4;
+    const bool matlab = file_format == KKD_MFILM_MATLAB;
+    std::string out; out.reserve((size_t)1 << 20);
+    bool ok = true;
+    char num[96];
+    for (uint32_t ch = 0; ch < channels; ++ch) {
+        if (matlab) {
+            if (ch == 0) out += var + " = [";
+            else out += "\n" + var + "(:, :, " + std::to_string(ch + 1) + ") = [";
+        } else if (ch == 0) out += var + (channels == 1 ? " = {{" : " = Transpose[{{{");
+        const float *ptr = pixels + ch;
+        for (uint32_t y = 0; y < height; ++y) {
+            for (uint32_t x = 0; x < width; ++x, ptr += channels) {
+                std::snprintf(num, sizeof(num), "%.*g", prec, (double)*ptr);
+                if (matlab) out += num;
+                else {
+                    std::string str(num);                          /* boost::replace_first(str, "e", "*^") */
+                    const size_t e = str.find('e');
+                    if (e != std::string::npos) str.replace(e, 1, "*^");
+                    out += str;
+                }
+                if (x + 1 < width) out += ", ";
+                else if (matlab) out += (y + 1 < height) ? ";\n\t" : "];\n";
+                else if (y + 1 < height) out += "},\n\t{";
+                else if (ch + 1 == channels) out += (channels == 1) ? "}};\n" : "}}}, {3,1,2}];\n";
+                else out += "}},\n\n\t{{";
+            }
+            if (out.size() >= ((size_t)1 << 20)) { ok = ok && std::fwrite(out.data(), 1, out.size(), f) == out.size(); out.clear(); }
+        }
+    }
+    ok = ok && std::fwrite(out.data(), 1, out.size(), f) == out.size();
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? KKD_OK : KKD_ERR_INVALID;
+}
+
 } /* extern "C" */
 
 /* ---- BSDF parameter extraction for the Mitsuba-side adapter (host only) -------------------------------------------

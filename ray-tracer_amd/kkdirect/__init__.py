@@ -297,6 +297,21 @@ def write_npy(path, pixels):
         raise KKDError(rc, "kkd_write_npy(%s) failed" % path)
 
 
+def write_mfilm_text(path, pixels, file_format="matlab", digits=4, variable="data"):
+    """MFilm's MATLAB (its default) / Mathematica output (reference src/films/mfilm.cpp:269-334) through kkd_write_mfilm_text;
+    pixels H x W [x C]; digits and variable as the plugin's parameters (mfilm.cpp:134-135)."""
+    px = np.ascontiguousarray(pixels, np.float32)
+    if px.ndim == 2:
+        px = px[..., None]
+    h, w, c = px.shape
+    fmt = {"matlab": abi.MFILM_MATLAB, "mathematica": abi.MFILM_MATHEMATICA}.get(str(file_format).lower())
+    if fmt is None:                                                                                # mfilm.cpp:129-132
+        raise KKDError(abi.KKD_ERR_INVALID, 'The "fileFormat" parameter must either be equal to "matlab", "mathematica" or "numpy"')
+    rc = load_library().kkd_write_mfilm_text(os.fsencode(path), px.ctypes.data_as(abi.pf32), w, h, c, fmt, int(digits), variable.encode())
+    if rc != 0:
+        raise KKDError(rc, "kkd_write_mfilm_text(%s) failed" % path)
+
+
 def _mesh_to_dict(m):
     nv, nt = int(m.n_verts), int(m.n_tris)
 

@@ -94,6 +94,7 @@ class RenderParams(C.Structure):
 
 INTEGRATOR_KK, INTEGRATOR_DIRECT, INTEGRATOR_PATH = 0, 1, 2
 SAMPLER_INDEPENDENT, SAMPLER_LDSAMPLER, SAMPLER_STRATIFIED = 0, 1, 2
+MFILM_MATLAB, MFILM_MATHEMATICA = 0, 1
 
 
 class Stats(C.Structure):
@@ -135,6 +136,7 @@ ENTRY_POINTS = {
     "kkd_develop": (C.c_int, [C.c_void_p, pf32, u32, u32, i32, pf32]),
     "kkd_write_pfm": (C.c_int, [C.c_char_p, pf32, u32, u32, i32]),
     "kkd_write_npy": (C.c_int, [C.c_char_p, pf32, u32, u32, u32]),
+    "kkd_write_mfilm_text": (C.c_int, [C.c_char_p, pf32, u32, u32, u32, C.c_int32, C.c_int32, C.c_char_p]),
     "kkd_write_rgbe": (C.c_int, [C.c_char_p, pf32, u32, u32, i32]),
     "kkd_write_exr": (C.c_int, [C.c_char_p, pf32, u32, u32, i32, i32, i32, C.c_char_p]),
     "kkd_parse_bsdf_stream": (C.c_int, [C.c_void_p, u64, C.POINTER(Material), u32, pu32]),

@@ -186,3 +186,50 @@ def test_high_quality_edges_gpu_matches_oracle():
         assert sg.samples == so.samples == 44 * 28 * 32
         np.testing.assert_allclose(film[..., 4], ref[..., 4], rtol=1e-4, atol=1e-4)
         assert helpers.rel_mse(helpers.develop(film), helpers.develop(ref)) < 1e-5
+
+
+# ---- MFilm text output (reference src/films/mfilm.cpp:269-334) ----
+# expected bytes written out by hand from the reference's loop: "os << float" at setprecision(4) prints 0.5, 1.234e-05, 1235, 1e+10
+
+_MF_IMG = np.array([[[0.5, 2, 3], [1.2344e-5, 5, 6]],
+                    [[1234.56, 8, 9], [1e10, 11, 12]]], np.float32)          # H = 2, W = 2, C = 3
+
+
+def test_write_mfilm_matlab_known_bytes(tmp_path):
+    p = tmp_path / "a.m"
+    kkdirect.write_mfilm_text(str(p), _MF_IMG)
+    assert p.read_bytes() == (b"data = [0.5, 1.234e-05;\n\t1235, 1e+10];\n"
+                              b"\ndata(:, :, 2) = [2, 5;\n\t8, 11];\n"
+                              b"\ndata(:, :, 3) = [3, 6;\n\t9, 12];\n")
+    kkdirect.write_mfilm_text(str(p), _MF_IMG[..., 0], digits=2, variable="img")                # one channel, other parameters
+    assert p.read_bytes() == b"img = [0.5, 1.2e-05;\n\t1.2e+03, 1e+10];\n"
+
+
+def test_write_mfilm_mathematica_known_bytes(tmp_path):
+    p = tmp_path / "b.m"
+    kkdirect.write_mfilm_text(str(p), _MF_IMG, file_format="mathematica")
+    assert p.read_bytes() == (b"data = Transpose[{{{0.5, 1.234*^-05},\n\t{1235, 1*^+10}},\n\n"
+                              b"\t{{2, 5},\n\t{8, 11}},\n\n"
+                              b"\t{{3, 6},\n\t{9, 12}}}, {3,1,2}];\n")
+    kkdirect.write_mfilm_text(str(p), _MF_IMG[..., :1], file_format="Mathematica")              # fileFormat is lower-cased, mfilm.cpp:93-94
+    assert p.read_bytes() == b"data = {{0.5, 1.234*^-05},\n\t{1235, 1*^+10}};\n"
+
+
+def test_write_mfilm_text_parses_back_and_edge_values(tmp_path):
+    img = np.random.RandomState(5).rand(7, 5, 4).astype(np.float32) * 100
+    img[0, 0, 0] = np.inf; img[1, 2, 3] = 0.0; img[2, 1, 1] = -3.5e-30
+    p = tmp_path / "c.m"
+    kkdirect.write_mfilm_text(str(p), img, digits=9)                                            # 9 digits identify a float32
+    text = p.read_text()
+    chans = [blk[blk.index("[") + 1:blk.index("]")] for blk in text.split("data")[1:]]
+    assert len(chans) == 4
+    back = np.stack([np.array([[float(v) for v in row.split(",")] for row in ch.split(";")], np.float32) for ch in chans], -1)
+    assert np.array_equal(back, img)
+    kkdirect.write_mfilm_text(str(p), np.full((1, 1), 0.125, np.float32), digits=0)             # 0 digits at the C ABI = the plugin's default 4
+    assert p.read_bytes() == b"data = [0.125];\n"
+    with pytest.raises(kkdirect.KKDError):
+        kkdirect.write_mfilm_text(str(p), img, file_format="numpy")
+    with pytest.raises(kkdirect.KKDError):
+        kkdirect.write_mfilm_text(str(tmp_path / "nodir" / "x.m"), img)
+    with pytest.raises(kkdirect.KKDError):
+        kkdirect.write_mfilm_text(str(p), img, digits=-1)
