@@ -486,9 +486,23 @@ void kkd_request_cancel(kkd_ctx *ctx);
  * (src/librender/renderqueue.cpp:119-141).  fn is called on the thread inside kkd_render / kkd_render_device, between
  * batches, with the number of work items (camera samples, including the padding of partial tiles) whose results are in
  * the film (completed on the device) and their total;
- * the last call of a finished render reports done == total.  fn == NULL removes the callback.  It must not call into ctx. */
+ * the last call of a finished render reports done == total.  fn == NULL removes the callback.  It must not call into ctx
+ * (kkd_request_cancel and kkd_request_flush excepted). */
 typedef void (*kkd_progress_fn)(void *user, uint64_t samples_done, uint64_t samples_total);
 int kkd_set_progress_callback(kkd_ctx *ctx, kkd_progress_fn fn, void *user);
+
+/* The film while the render runs: what `mitsuba -r <seconds>` does with its FlushThread (src/mitsuba/mitsuba.cpp:105-125 ->
+ * RenderQueue::flush, src/librender/renderqueue.cpp:73-78 -> Scene::flush = Film::develop, src/librender/scene.cpp:458-460).
+ * kkd_request_flush is asynchronous and thread-safe like kkd_request_cancel (and, like it, may be called from the progress
+ * callback); the render thread answers it between two batches: it lets the batches already queued finish, copies the film
+ * (width x height x 5 floats, the layout kkd_render returns) into a pinned host buffer of the context and calls fn on the
+ * render thread with the work items whose results the copy holds.  The buffer is valid during the call only; develop it
+ * with kkd_develop or write it with the kkd_write_* functions.  A request that arrives after the last batch was queued is
+ * dropped: the finished film follows anyway.  Costs one drain of the pipeline and one copy per request.  fn == NULL removes
+ * the callback.  Single context only: kkd_multi_* deliver the merged film at the end of the render. */
+typedef void (*kkd_flush_fn)(void *user, const float *film, uint32_t width, uint32_t height, uint64_t samples_done, uint64_t samples_total);
+int kkd_set_flush_callback(kkd_ctx *ctx, kkd_flush_fn fn, void *user);
+void kkd_request_flush(kkd_ctx *ctx);
 
 /* ---- several GPUs of one node behind one handle ---------------------------------------------------------------
  * What the reference does with its scheduler -- every worker renders blocks (src/librender/renderproc.cpp:68-86),

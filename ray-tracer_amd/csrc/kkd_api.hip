@@ -94,6 +94,8 @@ struct kkd_ctx {
     std::vector<hipEvent_t> events;
     std::vector<hipEvent_t> doneEvents;   /* one per batch in flight: recorded after the batch's splat (progress reports) */
     kkd_progress_fn progressFn = nullptr; void *progressUser = nullptr;
+    kkd_flush_fn flushFn = nullptr; void *flushUser = nullptr; std::atomic<int> flushReq{0};
+    float *flushHost = nullptr; size_t flushHostBytes = 0;     /* pinned copy of the film handed to flushFn */
     /* set up by kkd_create so that kkd_trace_device_noalloc never allocates: this device's scratch array, two timing
      * events, a pinned host copy of the counter shards */
     /* tile sharding: this context's tiles (Morton round-robin), cached for the last (grid, index, count) */
@@ -197,6 +199,14 @@ int kkd_set_progress_callback(kkd_ctx *ctx, kkd_progress_fn fn, void *user) {
     return KKD_OK;
 }
 
+int kkd_set_flush_callback(kkd_ctx *ctx, kkd_flush_fn fn, void *user) {
+    if (!ctx) return KKD_ERR_INVALID;
+    ctx->flushFn = fn; ctx->flushUser = user;
+    return KKD_OK;
+}
+
+void kkd_request_flush(kkd_ctx *ctx) { if (ctx) ctx->flushReq.store(1); }
+
 void kkd_destroy(kkd_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
@@ -212,6 +222,7 @@ void kkd_destroy(kkd_ctx *ctx) {
     for (hipEvent_t ev : ctx->doneEvents) hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->traceEv) if (ev) hipEventDestroy(ev);
     if (ctx->hostShards) hipHostFree(ctx->hostShards);
+    if (ctx->flushHost) hipHostFree(ctx->flushHost);
     for (hipStream_t s : ctx->laneStreams) if (s) hipStreamDestroy(s);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -521,7 +532,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     const uint32_t tileCount = rp->tile_count ? rp->tile_count : 1, tileIndex = rp->tile_count ? rp->tile_index : 0;
     if (tileIndex >= tileCount) return fail(ctx, KKD_ERR_INVALID, "tile_index must be < tile_count");
     KKD_HIP(ctx, hipSetDevice(ctx->device));
-    ctx->cancel.store(0);
+    ctx->cancel.store(0); ctx->flushReq.store(0);
 
     const int W = ctx->ds.sensor.cropW, H = ctx->ds.sensor.cropH;
     const int edge = ctx->ds.sensor.hqEdges ? ctx->ds.filter.border : 0;   /* Film::hasHighQualityEdges (renderproc.cpp:163-171) */
@@ -667,7 +678,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     /* progress: a ring of "batch done" events (a lane runs its batches in order, so at most a few are outstanding);
      * completed ones are polled between batches, never waited for */
     constexpr size_t kDoneRing = 16;
-    const bool report = ctx->progressFn != nullptr;
+    const bool report = ctx->progressFn != nullptr || ctx->flushFn != nullptr;   /* a flush is answered between batches: same pacing */
     while (report && ctx->doneEvents.size() < kDoneRing) { hipEvent_t e; KKD_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->doneEvents.push_back(e); }
     uint64_t doneCount[kDoneRing] = {}; bool donePending[kDoneRing] = {};
     uint64_t finishedSamples = 0;
@@ -679,7 +690,22 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
             if (wait) hipEventSynchronize(ctx->doneEvents[k]);
             if (hipEventQuery(ctx->doneEvents[k]) == hipSuccess) { donePending[k] = false; add += doneCount[k]; }
         }
-        if (add) { finishedSamples += add; ctx->progressFn(ctx->progressUser, std::min(finishedSamples, total), total); }
+        if (add) { finishedSamples += add; if (ctx->progressFn) ctx->progressFn(ctx->progressUser, std::min(finishedSamples, total), total); }
+    };
+    /* Film::develop during the render (Scene::flush, scene.cpp:458-460): drain what is queued, hand out a copy of the film */
+    auto serviceFlush = [&]() -> int {
+        const size_t bytes = (size_t)W * H * 5 * sizeof(float);
+        if (ctx->flushHostBytes < bytes) {
+            if (ctx->flushHost) { hipHostFree(ctx->flushHost); ctx->flushHost = nullptr; ctx->flushHostBytes = 0; }
+            if (hipHostMalloc((void **)&ctx->flushHost, bytes, hipHostMallocDefault) != hipSuccess) return fail(ctx, KKD_ERR_NOMEM, "flush: no pinned memory for the film copy");
+            ctx->flushHostBytes = bytes;
+        }
+        for (int l = 0; l < nLanes; ++l) KKD_HIP(ctx, hipStreamSynchronize(laneStream[l]));
+        pollProgress(false);
+        KKD_HIP(ctx, hipMemcpyAsync(ctx->flushHost, film, bytes, hipMemcpyDeviceToHost, st0));
+        KKD_HIP(ctx, hipStreamSynchronize(st0));
+        ctx->flushFn(ctx->flushUser, ctx->flushHost, (uint32_t)W, (uint32_t)H, std::min(finishedSamples, total), total);
+        return KKD_OK;
     };
     auto batchDone = [&](hipStream_t st, uint64_t index, uint64_t count) {      /* after the batch's splat has been queued */
         if (!report) return;
@@ -693,6 +719,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     for (uint64_t w0 = 0; w0 < total; w0 += batch, ++batchIndex) {
         if (ctx->cancel.load()) { cancelled = true; break; }
         pollProgress(false);
+        if (ctx->flushFn && ctx->flushReq.exchange(0)) { const int rcFlush = serviceFlush(); if (rcFlush != KKD_OK) return rcFlush; }
         const int lane = (int)(batchIndex % (uint64_t)nLanes);
         const hipStream_t st = laneStream[lane];
         const WaveBuffers &wb = wbL[lane]; const TraceContinuation &cont = contL[lane];

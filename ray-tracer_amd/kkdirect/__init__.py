@@ -101,6 +101,18 @@ class Context:
         self._progress = abi.PROGRESS_FN(lambda user, done, total: fn(done, total)) if fn else abi.PROGRESS_FN()
         self._check(self.lib.kkd_set_progress_callback(self.h, self._progress, None))
 
+    def set_flush_callback(self, fn):
+        """fn(film[H, W, 5] copy, samples_done, samples_total) answers request_flush() between two batches of a render: the film
+        so far, what Mitsuba's FlushThread develops (kkd_set_flush_callback); None removes it."""
+        def thunk(user, film, w, h, done, total):
+            fn(np.ctypeslib.as_array(film, shape=(h, w, 5)).copy(), done, total)
+        self._flush = abi.FLUSH_FN(thunk) if fn else abi.FLUSH_FN()
+        self._check(self.lib.kkd_set_flush_callback(self.h, self._flush, None))
+
+    def request_flush(self):
+        """asynchronous, thread-safe, allowed inside the progress callback (kkd_request_flush)"""
+        self.lib.kkd_request_flush(self.h)
+
     def render(self, spp, bsdf_samples=1, light_samples=1, hide_emitters=False, block_size=0, tile_index=0, tile_count=1,
                sample_first=0, integrator=abi.INTEGRATOR_KK, strict_normals=False, max_depth=-1, rr_depth=5,
                sampler=abi.SAMPLER_INDEPENDENT, sampler_dimension=0, sample_count_total=0):

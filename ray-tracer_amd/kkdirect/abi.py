@@ -83,6 +83,7 @@ class MultiConfig(C.Structure):
 SPLIT_TILE, SPLIT_SAMPLE = 0, 1
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64)
+FLUSH_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64)
 
 
 class RenderParams(C.Structure):
@@ -148,6 +149,8 @@ ENTRY_POINTS = {
     "kkd_mesh_free": (None, [C.POINTER(Mesh)]),
     "kkd_request_cancel": (None, [C.c_void_p]),
     "kkd_set_progress_callback": (C.c_int, [C.c_void_p, PROGRESS_FN, C.c_void_p]),
+    "kkd_set_flush_callback": (C.c_int, [C.c_void_p, FLUSH_FN, C.c_void_p]),
+    "kkd_request_flush": (None, [C.c_void_p]),
     "kkd_multi_create": (C.c_void_p, [C.POINTER(MultiConfig)]),
     "kkd_multi_scene_upload": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
     "kkd_multi_render": (C.c_int, [C.c_void_p, C.POINTER(RenderParams), pf32, C.POINTER(Stats)]),

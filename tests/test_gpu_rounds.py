@@ -120,3 +120,42 @@ def test_progress_callback_reports_finished_batches():
         ctx.set_progress_callback(None)
         ctx.render(8)
         assert len(calls) == n
+
+
+@pytest.mark.gpu
+def test_flush_hands_out_the_film_so_far():
+    """kkd_request_flush / kkd_set_flush_callback (what `mitsuba -r` does through FlushThread -> Scene::flush -> Film::develop):
+    the copy holds exactly the batches that are done -- pixels of finished tiles further than the filter border from unfinished
+    ones already have their final value, pixels of unfinished tiles further than the border from finished ones are empty."""
+    import kkdirect
+    from kkdirect import scenes
+    W = H = 128; bs = 32; spp = 32
+    sc = scenes.cornell_box(W, H)
+    with kkdirect.Context(device=0, seed=1, max_samples_in_flight=65536).upload(sc) as ctx:
+        flushes = []
+        ctx.set_flush_callback(lambda film, done, total: flushes.append((film, done, total)))
+        ctx.set_progress_callback(lambda done, total: ctx.request_flush())      # allowed from the callback, like a cancel request
+        final, st = ctx.render(spp)                                             # 524 288 samples: 8 batches of two tiles
+        assert len(flushes) >= 2
+        tile_of = (np.arange(H)[:, None] // bs) * (W // bs) + np.arange(W)[None, :] // bs     # tiles are rendered row-major
+        seen_partial = False
+        for film, done, total in flushes:
+            assert film.shape == (H, W, 5) and total == W * H * spp and 0 < done <= total and done % (bs * bs * spp) == 0
+            complete = tile_of < done // (bs * bs * spp)
+            pad = np.pad(complete, 2, mode="edge")
+            windows = np.stack([pad[dy:dy + H, dx:dx + W] for dy in range(5) for dx in range(5)])
+            inside, outside = windows.all(0), ~windows.any(0)
+            np.testing.assert_allclose(film[inside], final[inside], rtol=1e-5, atol=1e-7)
+            assert not film[outside].any()
+            assert (film <= final * (1 + 1e-5) + 1e-7).all()
+            seen_partial |= done < total
+        assert seen_partial
+        dones = [d for _, d, _ in flushes]
+        assert dones == sorted(dones)
+        n = len(flushes)
+        ctx.set_progress_callback(None)
+        ctx.request_flush()                       # a request from before the render is dropped at its start
+        again, _ = ctx.render(spp)
+        assert len(flushes) == n
+        np.testing.assert_allclose(again, final, rtol=1e-4, atol=1e-6)
+        ctx.set_flush_callback(None)
