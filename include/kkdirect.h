@@ -222,7 +222,14 @@ typedef struct kkd_render_params {
      * res x res cells (res^2 intervals) once over the pixel's samples in a shuffled order, jittered inside the cell; requested
      * arrays are Latin hypercubes (libcore/util.cpp:565-576).  res^2 = the sample count rounded up to a perfect square
      * (stratified.cpp:62-79 renders that many; this library renders the spp it is given and leaves the last strata empty, so
-     * callers pass a perfect square, as the Python mirror and the Mitsuba adapter do). */
+     * callers pass a perfect square, as the Python mirror and the Mitsuba adapter do);
+     * KKD_SAMPLER_HALTON / _HALTON_PLAIN = samplers/halton.cpp:240-384 with libcore/qmc.cpp:136-150 and samplers/faure.cpp:101-131:
+     * deterministic (the seed is not used).  Dimension d of a sample is the radical inverse of its index in the d-th prime base,
+     * digits permuted by Faure's permutations (HALTON, the plugin's default scramble = -1) or not (HALTON_PLAIN, scramble = 0;
+     * random permutations, scramble > 0, come from Mitsuba's SFMT and are not offered); dimensions 0 and 1 address the pixel
+     * through the 128-pixel tiling of setFilmResolution(res, blocked = true); sample arrays take dimensions 5 ... as in
+     * generate().  The prime table ends at dimension 1024, where the reference stops with an error; the path integrator's
+     * deeper vertices draw independent numbers instead. */
     uint32_t sampler;
     uint32_t sampler_dimension;   /* ldsampler / stratified 'dimension' (0 = their default 4) */
     /* Sampler::getSampleCount() of the whole render when this call renders only the share [sample_first, sample_first + spp) of
@@ -234,6 +241,8 @@ typedef struct kkd_render_params {
 #define KKD_SAMPLER_INDEPENDENT 0u
 #define KKD_SAMPLER_LDSAMPLER   1u
 #define KKD_SAMPLER_STRATIFIED  2u
+#define KKD_SAMPLER_HALTON      3u   /* halton plugin with its default scramble = -1: Faure permutations */
+#define KKD_SAMPLER_HALTON_PLAIN 4u  /* halton plugin with scramble = 0: plain radical inverses           */
 #define KKD_INTEGRATOR_KK     0u
 #define KKD_INTEGRATOR_DIRECT 1u
 #define KKD_INTEGRATOR_PATH   2u
@@ -357,6 +366,14 @@ int kkd_probe_ldsampler(uint64_t seed, uint32_t pixel, int kind, uint32_t index,
  * arrays of generate(), :158-162) with `resolution`^2 samples per pixel; flat_dim (even) = the dimension of the independent
  * stream whose values jitter the request inside its cell, as in a render. */
 int kkd_probe_stratified(uint64_t seed, uint32_t pixel, int kind, uint32_t index, uint32_t array_n, uint32_t resolution, uint32_t flat_dim, uint32_t count, float *out);
+/* HaltonSampler on a film of res_x x res_y pixels (setFilmResolution(res, true), generate(x, y), halton.cpp:240-384), samples
+ * 0 ... count-1 of pixel (x, y) -- kind 0: next2D at running dimension `dim` (out: count x 2; dim 0 = the position inside the
+ * pixel), kind 1: next1D at `dim` (out: count), kind 2: requested 2D array `dim` with array_n entries per sample when
+ * n_arrays are requested (out: count x array_n x 2).  faure != 0: scramble = -1 (Faure permutations), else scramble = 0. */
+int kkd_probe_halton(uint32_t res_x, uint32_t res_y, int32_t x, int32_t y, int faure, int kind, uint32_t dim, uint32_t array_n, uint32_t n_arrays, uint32_t count, float *out);
+/* The Faure permutation of `base` (2 ... 8161) as PermutationStorage::computeFaurePermutations builds it (samplers/faure.cpp:101-131);
+ * out: base entries. */
+int kkd_probe_faure_permutation(uint32_t base, uint16_t *out);
 
 /* ---- film develop and output: the step right after the path ---- */
 

@@ -58,6 +58,7 @@ int ora_render(ora_ctx *c, const kkd_render_params *p, uint64_t seed, int thread
     else if (!p->spp || p->bsdf_samples + p->light_samples == 0) return KKD_ERR_UNSUPPORTED;
     if (p->integrator == KKD_INTEGRATOR_KK && (!p->bsdf_samples || !p->light_samples)) return KKD_ERR_UNSUPPORTED;
     RenderParams rp{ p->spp, p->bsdf_samples, p->light_samples, p->hide_emitters != 0, p->block_size, p->tile_index, p->tile_count, p->sample_first, seed, p->integrator, p->strict_normals != 0, p->max_depth, p->rr_depth, p->sampler, p->sampler_dimension, p->sample_count_total };
+    rp.prepare(c->scene.sensor.cropW, c->scene.sensor.cropH);
     Stats st;
     auto t0 = std::chrono::steady_clock::now();
     c->scene.render(rp, film, &st, threads);
@@ -73,12 +74,13 @@ int ora_render(ora_ctx *c, const kkd_render_params *p, uint64_t seed, int thread
 /* Radiance of single camera samples, no film: pix = n x (x, y, sampleIndex); out = n x (r,g,b,alpha,sx,sy). */
 int ora_li_samples(ora_ctx *c, const kkd_render_params *p, uint64_t seed, const uint32_t *pix, uint64_t n, float *out) {
     RenderParams rp{ p->spp, p->bsdf_samples, p->light_samples, p->hide_emitters != 0, p->block_size, 0, 1, 0, seed, p->integrator, p->strict_normals != 0, p->max_depth, p->rr_depth, p->sampler, p->sampler_dimension, p->sample_count_total };
+    rp.prepare(c->scene.sensor.cropW, c->scene.sensor.cropH);
     const int W = c->scene.sensor.cropW;
     for (uint64_t i = 0; i < n; ++i) {
         uint32_t X = pix[3 * i], Y = pix[3 * i + 1], s = pix[3 * i + 2];
         const int edge = c->scene.hqEdges ? c->scene.filter.borderSize : 0;   /* same pixel key as Scene::render */
         SampleStream rng(seed, (uint32_t)(((int)Y + edge) * (W + 2 * edge) + ((int)X + edge)), s);
-        rp.configure(rng);
+        rp.configure(rng, (int)X, (int)Y);
         V2 jit = rng.next2D();
         V2 sp{ (Float)X + jit.x, (Float)Y + jit.y };
         Ray ray = c->scene.sensor.sampleRay(sp, 1.0f / std::sqrt((Float)rp.total()));
@@ -128,6 +130,17 @@ void ora_stratified(uint64_t seed, uint32_t pixel, int kind, uint32_t index, uin
         if (kind == 0) { s.dim2D = index; V2 v = s.next2D(); out[2 * j] = v.x; out[2 * j + 1] = v.y; }
         else if (kind == 1) { s.dim1D = index; out[j] = s.next1D(); }
         else for (uint32_t e = 0; e < arrayN; ++e) { V2 v = s.next2DArray(index, arrayN, e); out[2 * ((size_t)j * arrayN + e)] = v.x; out[2 * ((size_t)j * arrayN + e) + 1] = v.y; }
+    }
+}
+/* halton sampler on a resX x resY film, samples 0 ... count-1 of pixel (x, y): kind 0 = next2D at running dimension dim, 1 = next1D, 2 = array dim */
+void ora_halton(uint32_t resX, uint32_t resY, int32_t x, int32_t y, int faure, int kind, uint32_t dim, uint32_t arrayN, uint32_t nArrays, uint32_t count, float *out) {
+    HaltonCfg cfg; cfg.setFilmResolution((int)resX, (int)resY, faure != 0, nArrays);
+    for (uint32_t j = 0; j < count; ++j) {
+        SampleStream s(0, 0, j);
+        s.useHalton(&cfg, x, y); s.hdim = dim;
+        if (kind == 0) { V2 v = s.next2D(); out[2 * j] = v.x; out[2 * j + 1] = v.y; }
+        else if (kind == 1) out[j] = s.next1D();
+        else for (uint32_t e = 0; e < arrayN; ++e) { V2 v = s.next2DArray(dim, arrayN, e); out[2 * ((size_t)j * arrayN + e)] = v.x; out[2 * ((size_t)j * arrayN + e) + 1] = v.y; }
     }
 }
 void ora_clip_aabb(const float *tri9, const float *box6, float *out6) {

@@ -44,6 +44,8 @@ def lib():
         L.ora_ldsampler.restype = None
         L.ora_stratified.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, abi.pf32]
         L.ora_stratified.restype = None
+        L.ora_halton.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, abi.pf32]
+        L.ora_halton.restype = None
         L.ora_clip_aabb.argtypes = [abi.pf32, abi.pf32, abi.pf32]
         L.ora_bsdf_eval.argtypes = [C.c_void_p, C.c_int, abi.pf32, abi.pf32, abi.pf32, abi.pf32]
         L.ora_bsdf_sample.argtypes = [C.c_void_p, C.c_int, abi.pf32, abi.pf32, C.c_uint64, abi.pf32]
@@ -191,6 +193,13 @@ def stratified(seed, pixel, kind, index, array_n, res, flat_dim, count):
     """stratified sampler, shapes as ldsampler(); flat_dim: dimension of the independent stream that jitters the request"""
     out = np.zeros(count * (1 if kind == 1 else 2 * (array_n if kind == 2 else 1)), np.float32)
     lib().ora_stratified(seed, pixel, kind, index, array_n, res, flat_dim, count, _fp(out))
+    return out if kind == 1 else out.reshape((count, 2) if kind == 0 else (count, array_n, 2))
+
+
+def halton(res_x, res_y, x, y, faure, kind, dim, array_n, n_arrays, count):
+    """halton sampler, shapes as ldsampler(); dim = running dimension (kinds 0, 1) or array number (kind 2)"""
+    out = np.zeros(count * (1 if kind == 1 else 2 * (array_n if kind == 2 else 1)), np.float32)
+    lib().ora_halton(res_x, res_y, x, y, int(faure), kind, dim, array_n, n_arrays, count, _fp(out))
     return out if kind == 1 else out.reshape((count, 2) if kind == 0 else (count, array_n, 2))
 
 

@@ -282,6 +282,83 @@ inline uint32_t permuteIndex(uint32_t i, uint32_t l, uint32_t p) {
     return (i + p) % l;
 }
 
+/* ---- halton sampler (samplers/halton.cpp, libcore/qmc.cpp:136-150 RINV / SCRAMBLED_RINV, samplers/faure.cpp:101-131) ---- */
+struct HaltonCfg {
+    std::vector<uint32_t> primes; std::vector<std::vector<uint16_t>> faurePerm;   /* per prime-table entry */
+    bool faure = false; uint32_t pow[2] = { 1, 1 }, exp[2] = { 0, 0 }; uint64_t stride = 1, multInverse[2] = { 0, 0 }; uint32_t arrayEnd = 5;
+    static const HaltonCfg &tables() {
+        static const HaltonCfg t = [] {
+            HaltonCfg c;
+            for (uint32_t n = 2; c.primes.size() < 1024; ++n) {                       /* primeTable: the first 1024 primes (qmc.cpp:23) */
+                bool prime = true;
+                for (uint32_t d = 2; d * d <= n; ++d) if (n % d == 0) { prime = false; break; }
+                if (prime) c.primes.push_back(n);
+            }
+            const uint32_t maxBase = c.primes.back();
+            std::vector<std::vector<uint16_t>> perm(maxBase + 1);                     /* faure.cpp:101-131 */
+            perm[1] = { 0 }; perm[2] = { 0, 1 };
+            for (uint32_t b = 3; b <= maxBase; ++b) {
+                perm[b].resize(b);
+                if (b & 1) {
+                    const uint16_t cc = (uint16_t)((b - 1) / 2);
+                    for (uint16_t i = 0; i < b; ++i) {
+                        if (i == cc) perm[b][i] = cc;
+                        else { const uint16_t f = perm[b - 1][i - (int)(i > cc)]; perm[b][i] = (uint16_t)(f + (int)(f >= cc)); }
+                    }
+                } else {
+                    const uint16_t cc = (uint16_t)(b / 2);
+                    for (uint16_t i = 0; i < b; ++i) perm[b][i] = (uint16_t)(i < cc ? 2 * perm[cc][i] : 2 * perm[cc][i - cc] + 1);
+                }
+            }
+            for (uint32_t pr : c.primes) c.faurePerm.push_back(perm[pr]);
+            return c;
+        }();
+        return t;
+    }
+    static void extendedGCD(uint64_t a, uint64_t b, int64_t &x, int64_t &y) {        /* halton.cpp:217-227 */
+        if (b == 0) { x = 1; y = 0; return; }
+        int64_t d = (int64_t)(a / b), x_, y_;
+        extendedGCD(b, a % b, x_, y_);
+        x = y_; y = x_ - d * y_;
+    }
+    static uint64_t multiplicativeInverse(int64_t a, int64_t n) { int64_t x, y; extendedGCD((uint64_t)a, (uint64_t)n, x, y); int64_t r = x % n; return (uint64_t)(r < 0 ? r + n : r); }
+    /* setFilmResolution(res, blocked = true), halton.cpp:240-263 */
+    void setFilmResolution(int resX, int resY, bool useFaure, uint32_t nArrays) {
+        const int res[2] = { resX, resY }; stride = 1; faure = useFaure;
+        for (int i = 0; i < 2; ++i) {
+            const int prime = i ? 3 : 2; int value = 1, e = 0;
+            while (value < std::min(res[i], 128)) { value *= prime; ++e; }
+            pow[i] = (uint32_t)value; exp[i] = (uint32_t)e; stride *= (uint64_t)value;
+        }
+        multInverse[0] = multiplicativeInverse(pow[1], pow[0]); multInverse[1] = multiplicativeInverse(pow[0], pow[1]);
+        arrayEnd = 5 + 2 * nArrays;
+    }
+    Float radicalInverse(uint32_t dim, uint64_t index) const {                       /* qmc.cpp:136-165, 198-1228 */
+        const HaltonCfg &t = tables();
+        const uint32_t base = t.primes[dim];
+        const Float radical = (Float)1 / (Float)base;
+        uint64_t value = 0; Float factor = 1.0f;
+        while (index) {
+            const uint64_t next = index / base, digit = index - next * base;
+            value = value * base + (faure ? (uint64_t)t.faurePerm[dim][digit] : digit);
+            factor *= radical; index = next;
+        }
+        const Float inverse = (Float)value * factor;
+        return std::min(inverse, 0x1.fffffep-1f);
+    }
+    static uint32_t tilePos(int p) { return (uint32_t)(((p % 128) + 128) % 128); }   /* pos % MAX_RESOLUTION, made non-negative */
+    uint64_t pixelOffset(uint32_t px, uint32_t py) const {                           /* halton.cpp:282-294; Faure(2), Faure(3) = identity */
+        if (stride <= 1) return 0;
+        uint64_t offset = 0; const uint32_t pos[2] = { px, py };
+        for (int i = 0; i < 2; ++i) {
+            const uint64_t base = i ? 3 : 2; uint64_t inverse = pos[i], index = 0;
+            for (uint32_t d = exp[i]; d; --d) { const uint64_t digit = inverse % base; inverse /= base; index = index * base + digit; }
+            offset += index * (stride / pow[i]) * multInverse[i];
+        }
+        return offset % stride;
+    }
+};
+
 /* One camera sample's Sampler: independent (samplers/independent.cpp:82-103) or ldsampler (samplers/ldsampler.cpp:148-229).
  * ldsampler: request k of the sample's 2D (1D) requests, k < ldDim, reads entry `sample` of the pixel's k-th scrambled and
  * shuffled (0,2)-sequence (van der Corput sequence); next2DArray(a, n, e) reads entry sample * n + e of requested array a; the
@@ -294,6 +371,10 @@ struct SampleStream {
     uint32_t cache[4]; int cachedBlock;
     uint32_t ldSet = 0, ldDim = 0, dim2D = 0, dim1D = 0;       /* ldSet = 0: independent */
     uint32_t stratRes = 0;                                     /* > 0: stratified with stratRes^2 samples per pixel (ldSet = stratRes^2) */
+    const HaltonCfg *hal = nullptr; int hX = 0, hY = 0;        /* halton: one running dimension hdim over the sample's requests (m_dimension) */
+    uint32_t hdim = 0;
+    void useHalton(const HaltonCfg *cfg, int X, int Y) { hal = cfg; hX = X; hY = Y; }
+    uint64_t haltonIndex(uint64_t j) const { return hal->pixelOffset(HaltonCfg::tilePos(hX), HaltonCfg::tilePos(hY)) + hal->stride * j; }
     SampleStream(uint64_t seed, uint32_t pix, uint32_t smp)
         : pixel(pix), sample(smp), seedLo((uint32_t)seed), seedHi((uint32_t)(seed >> 32)), dim(0), cachedBlock(-1) {}
     void useLdSampler(uint32_t setSize, uint32_t dimension) { ldSet = setSize; ldDim = dimension; }
@@ -318,6 +399,11 @@ struct SampleStream {
     }
     Float next1D() {
         const uint32_t req = dim1D++;
+        if (hal) {                                                                   /* halton.cpp:352-362 */
+            if (hdim >= 5 && hdim < hal->arrayEnd) hdim = hal->arrayEnd;
+            if (hdim < 1024) { dim += 1; return hal->radicalInverse(hdim++, haltonIndex(sample)); }
+            hdim += 1; return independent1D();                                       /* past the prime table: the reference stops with an error */
+        }
         if (stratRes && req < ldDim) {
             const Float xi = independent1D();
             uint32_t r[4]; streamWords(2 * req + 1, r);
@@ -332,6 +418,18 @@ struct SampleStream {
     }
     V2 next2D() {
         const uint32_t req = dim2D++;
+        if (hal) {                                                                   /* halton.cpp:364-384 */
+            if (hdim >= 5 && hdim < hal->arrayEnd) hdim = hal->arrayEnd;
+            if (hdim + 1 < 1024) {
+                dim += 2;
+                const uint64_t index = haltonIndex(sample);
+                const uint32_t d = hdim; hdim += 2;
+                const Float a = hal->radicalInverse(d, index), b = hal->radicalInverse(d + 1, index);
+                if (d == 0) return V2{ a * (Float)hal->pow[0] - (Float)HaltonCfg::tilePos(hX), b * (Float)hal->pow[1] - (Float)HaltonCfg::tilePos(hY) };
+                return V2{ a, b };
+            }
+            hdim += 2; Float a = independent1D(); Float b = independent1D(); return V2{ a, b };
+        }
         if (stratRes && req < ldDim) {
             const Float xa = independent1D(), xb = independent1D();
             uint32_t r[4]; streamWords(2 * req, r);
@@ -349,6 +447,11 @@ struct SampleStream {
     }
     /* element e of this sample's n-element slice of requested array `array` (Sampler::next2DArray, sampler.cpp:79-90) */
     V2 next2DArray(uint32_t array, uint32_t n, uint32_t e) {
+        if (hal) {                                                                   /* halton.cpp:309-326: dimensions 5 + 2a, 6 + 2a */
+            dim += 2;
+            const uint64_t index = haltonIndex((uint64_t)sample * n + e);
+            return V2{ hal->radicalInverse(5 + 2 * array, index), hal->radicalInverse(6 + 2 * array, index) };
+        }
         if (stratRes) {
             const Float xa = independent1D(), xb = independent1D();
             uint32_t r[4]; streamWords(0x10000u + array, r);

@@ -514,12 +514,18 @@ struct RenderParams { uint32_t spp, nB, nL; bool hideEmitters; uint32_t blockSiz
                       uint32_t sampler = 0, samplerDimension = 0, sampleCountTotal = 0;
                       uint32_t total() const { return sampleCountTotal ? sampleCountTotal : spp; }                /* Sampler::getSampleCount() */
                       static uint32_t pow2ceil(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
-                      void configure(SampleStream &rng) const {                                                  /* ldsampler.cpp:76-87 */
+                      HaltonCfg halton;                                                                          /* filled by prepare() */
+                      void prepare(int cropW, int cropH) {                                                       /* Integrator::configureSampler, integrator.cpp:37-41 */
+                          if (sampler == KKD_SAMPLER_HALTON || sampler == KKD_SAMPLER_HALTON_PLAIN)
+                              halton.setFilmResolution(cropW, cropH, sampler == KKD_SAMPLER_HALTON, integrator == KKD_INTEGRATOR_PATH ? 0u : (nB > 1 ? 1u : 0u) + (nL > 1 ? 1u : 0u));
+                      }
+                      void configure(SampleStream &rng, int X, int Y) const {                                    /* ldsampler.cpp:76-87 */
                           if (sampler == KKD_SAMPLER_LDSAMPLER) rng.useLdSampler(pow2ceil(total()), samplerDimension ? samplerDimension : 4u);
                           if (sampler == KKD_SAMPLER_STRATIFIED) {                                               /* stratified.cpp:62-79 */
                               uint32_t res = 1; while ((uint64_t)res * res < total()) ++res;
                               rng.useStratified(res, samplerDimension ? samplerDimension : 4u);
                           }
+                          if (sampler == KKD_SAMPLER_HALTON || sampler == KKD_SAMPLER_HALTON_PLAIN) rng.useHalton(&halton, X, Y);
                       } };
 struct Stats { std::atomic<uint64_t> samples{0}, raysClosest{0}, raysShadow{0}, nodes{0}, tris{0}; };
 
@@ -847,7 +853,7 @@ inline V3 Scene::LiPath(const Ray &r, SampleStream &rng, const RenderParams &rp,
         if (shape.emitter >= 0 && emitted && (!rp.hideEmitters || scattered))            /* :148-150 */
             Li += throughput * emitterEvalArea(emitters[shape.emitter], its, -ray.d);
         if ((depth >= rp.maxDepth && rp.maxDepth > 0) || (rp.strictNormals && dot(ray.d, its.geoFrame.n) * its.wi.z >= 0)) break;   /* :156-165 */
-        rng.dim = 2u + 6u * (uint32_t)(depth - 1); rng.dim2D = 1u + 2u * (uint32_t)(depth - 1);   /* request numbers are fixed per vertex */
+        rng.dim = 2u + 6u * (uint32_t)(depth - 1); rng.hdim = rng.dim; rng.dim2D = 1u + 2u * (uint32_t)(depth - 1);   /* request numbers are fixed per vertex */
         const uint32_t btype = bsdfs.getType(bsdf);
         DirectRec dRec; dRec.ref = its.p; dRec.refN = (btype & (ETransmission | EBackSide)) ? V3(0.f) : its.shFrame.n;
         {                                                                                /* :172-200 */
@@ -938,7 +944,7 @@ inline void Scene::render(const RenderParams &rp, float *film, Stats *st, int nT
                 const int X = ox + px, Y = oy + py;
                 for (uint32_t j = 0; j < rp.spp; ++j) {
                     SampleStream rng(rp.seed, (uint32_t)((Y + edge) * EW + (X + edge)), rp.sampleFirst + j);
-                    rp.configure(rng);
+                    rp.configure(rng, X, Y);
                     V2 jit = rng.next2D();
                     V2 samplePos{ (Float)X + jit.x, (Float)Y + jit.y };
                     Ray ray = sensor.sampleRay(samplePos, 1.0f / std::sqrt((Float)rp.total()));   /* integrator.cpp:144-145, 181 */

@@ -99,6 +99,7 @@ struct kkd_ctx {
     /* set up by kkd_create so that kkd_trace_device_noalloc never allocates: this device's scratch array, two timing
      * events, a pinned host copy of the counter shards */
     /* tile sharding: this context's tiles (Morton round-robin), cached for the last (grid, index, count) */
+    DevBuf haltonTables;       /* halton sampler: primes, offsets, Faure permutations (uploaded by the first render that uses it) */
     DevBuf tileList; std::vector<uint32_t> tileListHost; uint32_t tileKey[4] = { 0, 0, 0, 0 };
     void *noallocScratch = nullptr;
     hipEvent_t traceEv[2] = { nullptr, nullptr };
@@ -181,6 +182,31 @@ int kkd_probe_stratified(uint64_t seed, uint32_t pixel, int kind, uint32_t index
     return KKD_OK;
 }
 
+int kkd_probe_halton(uint32_t res_x, uint32_t res_y, int32_t x, int32_t y, int faure, int kind, uint32_t dim, uint32_t array_n, uint32_t n_arrays, uint32_t count, float *out) {
+    if (!out || !res_x || !res_y || kind < 0 || kind > 2 || (kind == 2 && (!array_n || dim >= n_arrays)) || (kind != 2 && dim + (kind == 0 ? 1u : 0u) >= kHaltonDims)) return KKD_ERR_INVALID;
+    static const std::vector<uint32_t> tables = [] { std::vector<uint32_t> t; haltonTables(t); return t; }();
+    HaltonSetup h; haltonSetup((int)res_x, (int)res_y, n_arrays, faure != 0, tables.data(), h);
+    for (uint32_t j = 0; j < count; ++j) {
+        if (kind == 0) { const f2 v = haltonSample2D(h, x, y, j, haltonSkipArrays(h, dim)); out[2 * j] = v.x; out[2 * j + 1] = v.y; }
+        else if (kind == 1) out[j] = haltonSample1D(h, x, y, j, haltonSkipArrays(h, dim));
+        else for (uint32_t e = 0; e < array_n; ++e) {
+            const f2 v = haltonArray2D(h, x, y, dim, (uint64_t)j * array_n + e);
+            out[2 * ((size_t)j * array_n + e)] = v.x; out[2 * ((size_t)j * array_n + e) + 1] = v.y;
+        }
+    }
+    return KKD_OK;
+}
+
+int kkd_probe_faure_permutation(uint32_t base, uint16_t *out) {
+    if (!out || base < 2) return KKD_ERR_INVALID;
+    static const std::vector<uint32_t> tables = [] { std::vector<uint32_t> t; haltonTables(t); return t; }();
+    for (uint32_t d = 0; d < kHaltonDims; ++d) if (tables[d] == base) {
+        std::memcpy(out, reinterpret_cast<const uint16_t *>(tables.data() + 2 * kHaltonDims) + tables[kHaltonDims + d], base * sizeof(uint16_t));
+        return KKD_OK;
+    }
+    return KKD_ERR_INVALID;     /* only the permutations of the prime bases are kept (faure.cpp:57-63) */
+}
+
 int kkd_probe_rfilter(int rfilter_type, float radius, const float *param2, float *values32, float *scale_factor, int *border) {
     if (!param2 || !values32 || !scale_factor || !border || rfilter_type < 0 || rfilter_type > KKD_RFILTER_LANCZOS || !(radius > 0.f)) return KKD_ERR_INVALID;
     DFilter f;
@@ -216,7 +242,7 @@ void kkd_destroy(kkd_ctx *ctx) {
                       &ctx->emitters, &ctx->emitterCdf, &ctx->areaCdf, &ctx->rtTables, &ctx->envTexels, &ctx->envCdfRows, &ctx->envCdfCols,
                       &ctx->envRowWeights, &ctx->contRecs, &ctx->contStacks, &ctx->contCount, &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->shadowRays,
                       &ctx->occluded, &ctx->lrec, &ctx->film, &ctx->counters, &ctx->apiRays, &ctx->apiHits,
-                      &ctx->envGuideRows, &ctx->envGuideCols, &ctx->emitterGuide, &ctx->areaGuide, &ctx->pathAlive, &ctx->pBsdfRays, &ctx->pBrec, &ctx->pRefN, &ctx->pShadowRays, &ctx->pLrec, &ctx->pSampleIdx, &ctx->tileList, &ctx->envEwaLut };
+                      &ctx->envGuideRows, &ctx->envGuideCols, &ctx->emitterGuide, &ctx->areaGuide, &ctx->pathAlive, &ctx->pBsdfRays, &ctx->pBrec, &ctx->pRefN, &ctx->pShadowRays, &ctx->pLrec, &ctx->pSampleIdx, &ctx->tileList, &ctx->envEwaLut, &ctx->haltonTables };
     for (DevBuf *b : all) b->release();
     for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->doneEvents) hipEventDestroy(ev);
@@ -512,10 +538,10 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     if (rp->spp == 0) return fail(ctx, KKD_ERR_INVALID, "spp must be positive");
     /* kk/direct.cpp:165-166 divides by both counts: zero is not a meaningful configuration */
     if (rp->integrator > KKD_INTEGRATOR_PATH) return fail(ctx, KKD_ERR_INVALID, "unknown integrator");
-    if (rp->sampler > KKD_SAMPLER_STRATIFIED) return fail(ctx, KKD_ERR_INVALID, "unknown sampler");
+    if (rp->sampler > KKD_SAMPLER_HALTON_PLAIN) return fail(ctx, KKD_ERR_INVALID, "unknown sampler");
     if (rp->sample_count_total && (uint64_t)rp->sample_first + rp->spp > rp->sample_count_total)
         return fail(ctx, KKD_ERR_INVALID, "sample_first + spp exceeds sample_count_total");
-    if (rp->sampler != KKD_SAMPLER_INDEPENDENT && (uint64_t)(rp->sample_count_total ? rp->sample_count_total : rp->spp) * 64u > 0x40000000ull)
+    if ((rp->sampler == KKD_SAMPLER_LDSAMPLER || rp->sampler == KKD_SAMPLER_STRATIFIED) && (uint64_t)(rp->sample_count_total ? rp->sample_count_total : rp->spp) * 64u > 0x40000000ull)
         return fail(ctx, KKD_ERR_UNSUPPORTED, "ldsampler / stratified: more than 2^24 samples per pixel");
     const bool pathMode = rp->integrator == KKD_INTEGRATOR_PATH;
     /* MonteCarloIntegrator (librender/integrator.cpp:190-233): maxDepth = -1 or > 0, rrDepth > 0 */
@@ -641,6 +667,16 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     if (rp->sampler == KKD_SAMPLER_STRATIFIED) {                                                     /* stratified.cpp:62-79 */
         uint32_t res = 1; while ((uint64_t)res * res < sampleCountTotal) ++res;
         bp.samplerRes = res; bp.samplerSet = res * res;
+    }
+    if (rp->sampler == KKD_SAMPLER_HALTON || rp->sampler == KKD_SAMPLER_HALTON_PLAIN) {
+        if (!ctx->haltonTables.p) {
+            std::vector<uint32_t> words; haltonTables(words);
+            const int rcUp = upload(ctx, ctx->haltonTables, words.data(), words.size());
+            if (rcUp != KKD_OK) return rcUp;
+            KKD_HIP(ctx, hipStreamSynchronize(ctx->stream));      /* `words` is read by an asynchronous copy */
+        }
+        /* Integrator::configureSampler (librender/integrator.cpp:37-41): the crop size, blocked; arrays as kk/direct.cpp:44-47 request them */
+        haltonSetup(W, H, pathMode ? 0u : (nB > 1u ? 1u : 0u) + (nL > 1u ? 1u : 0u), rp->sampler == KKD_SAMPLER_HALTON, (const uint32_t *)ctx->haltonTables.p, bp.halton);
     }
     bp.integrator = rp->integrator; bp.strictNormals = rp->strict_normals != 0;
     bp.maxDepth = rp->max_depth; bp.rrDepth = rp->rr_depth; bp.depth = 1;

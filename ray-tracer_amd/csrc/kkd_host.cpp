@@ -613,6 +613,77 @@ bool flattenScene(const kkd_scene_desc *sd, HostScene &hs, std::string &err, int
 
 /* ---- film output (host only) ------------------------------------------------------------------------------------ */
 #include <cstdio>
+namespace kkd {
+/* ---- halton sampler tables (host) -------------------------------------------------------------------------------------------
+ * primeTable of libcore/qmc.cpp:23 is the first 1024 primes (2 ... 8161): sieved here.  Faure permutations by the dynamic
+ * programme of samplers/faure.cpp:101-131 (Faure 1992) over all bases up to the largest prime, then those of the primes are
+ * kept (faure.cpp:36-63). */
+void haltonTables(std::vector<uint32_t> &words) {
+    std::vector<uint32_t> primes;
+    {
+        const uint32_t limit = 8200;
+        std::vector<char> composite(limit + 1, 0);
+        for (uint32_t i = 2; i <= limit && primes.size() < kHaltonDims; ++i) {
+            if (composite[i]) continue;
+            primes.push_back(i);
+            for (uint32_t j = i * i; j <= limit; j += i) composite[j] = 1;
+        }
+    }
+    const uint32_t maxBase = primes.back();
+    std::vector<std::vector<uint16_t>> perm(maxBase + 1);
+    perm[1] = { 0 }; perm[2] = { 0, 1 };
+    for (uint32_t b = 3; b <= maxBase; ++b) {
+        perm[b].resize(b);
+        if (b & 1u) {
+            const uint32_t c = (b - 1) / 2;
+            for (uint32_t i = 0; i < b; ++i) {
+                if (i == c) perm[b][i] = (uint16_t)c;
+                else { const uint32_t f = perm[b - 1][i - (i > c ? 1u : 0u)]; perm[b][i] = (uint16_t)(f + (f >= c ? 1u : 0u)); }
+            }
+        } else {
+            const uint32_t c = b / 2;
+            for (uint32_t i = 0; i < b; ++i) perm[b][i] = (uint16_t)(i < c ? 2u * perm[c][i] : 2u * perm[c][i - c] + 1u);
+        }
+    }
+    size_t total = 0; for (uint32_t pr : primes) total += pr;
+    words.assign(2 * kHaltonDims + (total + 1) / 2, 0u);
+    uint16_t *dst = reinterpret_cast<uint16_t *>(words.data() + 2 * kHaltonDims);
+    size_t ofs = 0;
+    for (uint32_t d = 0; d < kHaltonDims; ++d) {
+        words[d] = primes[d]; words[kHaltonDims + d] = (uint32_t)ofs;
+        std::memcpy(dst + ofs, perm[primes[d]].data(), primes[d] * sizeof(uint16_t));
+        ofs += primes[d];
+    }
+}
+
+namespace {
+void extendedGcd(uint64_t a, uint64_t b, int64_t &x, int64_t &y) {          /* halton.cpp:217-227 */
+    if (b == 0) { x = 1; y = 0; return; }
+    const int64_t d = (int64_t)(a / b); int64_t x_, y_;
+    extendedGcd(b, a % b, x_, y_);
+    x = y_; y = x_ - d * y_;
+}
+uint64_t multiplicativeInverse(int64_t a, int64_t n) {                       /* halton.cpp:234-238, math::modulo */
+    int64_t x, y; extendedGcd((uint64_t)a, (uint64_t)n, x, y);
+    int64_t r = x % n; if (r < 0) r += n;
+    return (uint64_t)r;
+}
+}
+void haltonSetup(int resX, int resY, uint32_t nArrays, bool faure, const uint32_t *tables, HaltonSetup &h) {
+    const int res[2] = { resX, resY }; uint64_t stride = 1;
+    for (int i = 0; i < 2; ++i) {
+        const int prime = i ? 3 : 2; int value = 1, exp = 0;
+        while (value < std::min(res[i], 128)) { value *= prime; ++exp; }    /* MAX_RESOLUTION, halton.cpp:29, 252-255 */
+        h.pow[i] = (uint32_t)value; h.exp[i] = (uint32_t)exp; stride *= (uint64_t)value;
+    }
+    h.stride = (uint32_t)stride;
+    const uint64_t inv[2] = { multiplicativeInverse(h.pow[1], h.pow[0]), multiplicativeInverse(h.pow[0], h.pow[1]) };
+    for (int i = 0; i < 2; ++i) h.mul[i] = (stride / h.pow[i]) * inv[i];
+    h.arrayEnd = 5u + 2u * nArrays;                                          /* halton.cpp:276-278 */
+    h.tables = tables; h.faure = faure ? 1u : 0u; h.pad = 0;
+}
+} /* namespace kkd */
+
 extern "C" {
 
 /* Bitmap::writePFM, src/libcore/bitmap.cpp:3804-3843 */

@@ -46,6 +46,10 @@ bool flattenScene(const kkd_scene_desc *sd, HostScene &hs, std::string &err, int
 void roughTransmittanceTable(int distr, float alpha, float eta, float *trans100, float *diffTrans);
 
 void configureFilter(int type, float radius, const float *param, DFilter &f);
+/* halton sampler: [1024 primes][1024 offsets][Faure permutations as uint16] (libcore/qmc.cpp:23, samplers/faure.cpp:25-142) */
+void haltonTables(std::vector<uint32_t> &words);
+/* HaltonSampler::setFilmResolution(res, blocked = true) + the end of the dimensions reserved to nArrays 2D arrays (halton.cpp:240-279) */
+void haltonSetup(int resX, int resY, uint32_t nArrays, bool faure, const uint32_t *tables, HaltonSetup &h);
 
 uint16_t floatToHalf(float f);
 float halfToFloat(uint16_t h);

@@ -70,20 +70,30 @@ __device__ __forceinline__ SampleId mapWorkItem(const BatchParams &bp, uint32_t 
  * beyond the sampler's 'dimension' falls back to, ldsampler.cpp:214-228, stratified.cpp:186-187, 201-205), `req` the running
  * number of the 2D (1D) request within the sample, (array, n, e) element e of the sample's n-element slice of requested array
  * `array`.  mode: KKD_SAMPLER_* -- a compile-time constant in kShade, whose register budget has no room for all samplers. */
+__device__ __forceinline__ bool isHalton(uint32_t mode) { return mode == KKD_SAMPLER_HALTON || mode == KKD_SAMPLER_HALTON_PLAIN; }
+/* halton: one running dimension over all requests of a sample (m_dimension): the kk / direct plugins only make 2D requests, so it is
+ * 2 * req; the path plugin's requests sit at fixed dimensions per vertex, the independent stream's (`flat`).  Beyond the prime
+ * table (the reference stops with an error there, halton.cpp:356-358) the independent stream takes over. */
+__device__ __forceinline__ uint32_t haltonDim(const BatchParams &bp, uint32_t flat, uint32_t req2) {
+    return haltonSkipArrays(bp.halton, bp.integrator == KKD_INTEGRATOR_PATH ? flat : req2);
+}
 __device__ __forceinline__ f2 draw2D(const BatchParams &bp, const SampleId &s, uint32_t flat, uint32_t req, uint32_t mode) {
     if (mode == KKD_SAMPLER_LDSAMPLER && req < bp.samplerDim) return ldSample2D(bp.seed, s.pixel, 2u * req, s.sample, bp.samplerSet);
+    if (isHalton(mode)) { const uint32_t d = haltonDim(bp, flat, 2u * req); if (d + 1u < kHaltonDims) return haltonSample2D(bp.halton, s.X, s.Y, s.sample, d); }
     const f2 u = sample2D(bp.seed, s.pixel, s.sample, flat);
     if (mode == KKD_SAMPLER_STRATIFIED && req < bp.samplerDim) return stratSample2D(bp.seed, s.pixel, 2u * req, s.sample, bp.samplerRes, u);
     return u;
 }
 __device__ __forceinline__ f2 draw2DArray(const BatchParams &bp, const SampleId &s, uint32_t flat, uint32_t array, uint32_t n, uint32_t e, uint32_t mode) {
     if (mode == KKD_SAMPLER_LDSAMPLER) return ldSample2D(bp.seed, s.pixel, 0x10000u + array, s.sample * n + e, bp.samplerSet * n);
+    if (isHalton(mode)) return haltonArray2D(bp.halton, s.X, s.Y, array, (uint64_t)s.sample * n + e);
     const f2 u = sample2D(bp.seed, s.pixel, s.sample, flat);
     if (mode == KKD_SAMPLER_STRATIFIED) return latinHypercube2D(bp.seed, s.pixel, 0x10000u + array, s.sample * n + e, bp.samplerSet * n, u);
     return u;
 }
 __device__ __forceinline__ float draw1D(const BatchParams &bp, const SampleId &s, uint32_t flat, uint32_t req, uint32_t mode) {
     if (mode == KKD_SAMPLER_LDSAMPLER && req < bp.samplerDim) return ldSample1D(bp.seed, s.pixel, 2u * req + 1u, s.sample, bp.samplerSet);
+    if (isHalton(mode)) { const uint32_t d = haltonDim(bp, flat, flat); if (d < kHaltonDims) return haltonSample1D(bp.halton, s.X, s.Y, s.sample, d); }
     const float u = sample2D(bp.seed, s.pixel, s.sample, flat).x;
     if (mode == KKD_SAMPLER_STRATIFIED && req < bp.samplerDim) return stratSample1D(bp.seed, s.pixel, 2u * req + 1u, s.sample, bp.samplerRes, u);
     return u;
@@ -111,7 +121,9 @@ __device__ __forceinline__ void countTraversal(uint32_t nn, uint32_t nt, DeviceC
 #define KKD_PRIMARY_RAYS 2     /* rays per lane of the packet walk of the primary rays: the walk is bound by its scalar side, which is
                                   paid per wave -- measured on C2: 1: 28.7 ms, 2: 21.3 ms, 3: 22.0 ms, 4: 21.8 ms per frame */
 #endif
-template <bool COUNT, bool PROJ, bool PACKET, int STACK, int BLOCK>
+/* INDEP: the independent sampler, compiled without the other samplers' code (with them behind a run-time branch the packet walk
+ * of C4 took 179 instead of 173 ms per step) */
+template <bool COUNT, bool PROJ, bool PACKET, bool INDEP, int STACK, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, !PACKET || KKD_PRIMARY_RAYS == 1 ? 8 : (KKD_PRIMARY_RAYS == 2 ? 5 : 3)) kPrimary(DScene sc, BatchParams bp, DHit *__restrict__ hits, DeviceCounters *ctr) {
     /* PACKET: one wave-uniform stack per wave; else one stack per lane */
     __shared__ uint32_t sstack[PACKET ? (BLOCK / 64) * kMaxTraversalStack : STACK * BLOCK];
@@ -126,7 +138,7 @@ __global__ void __launch_bounds__(BLOCK, !PACKET || KKD_PRIMARY_RAYS == 1 ? 8 : 
         ray[r].maxt = -1.f; ray[r].mint = 0.f; ray[r].ox = ray[r].oy = ray[r].oz = 0.f; ray[r].dx = ray[r].dy = 0.f; ray[r].dz = 1.f;
         float sx, sy;
         active[r] = s.active;
-        if (s.active) ray[r] = primaryRay(sc, bp, s, sx, sy, bp.sampler);
+        if (s.active) ray[r] = primaryRay(sc, bp, s, sx, sy, INDEP ? KKD_SAMPLER_INDEPENDENT : bp.sampler);
     }
     const void *triTable = PROJ ? (const void *)sc.projTris : (const void *)sc.tris;
     if (PACKET) traversePacket<COUNT, PROJ, R>(sc.wideNodes, triTable, ray, sstack + (threadIdx.x >> 6) * kMaxTraversalStack, h, nn, nt);
@@ -660,6 +672,7 @@ __device__ __forceinline__ void splatGroup(float *__restrict__ film, const float
 }
 
 /* ---- K5: resolve + splat ---------------------------------------------------------------------------- */
+template <bool INDEP>   /* as kPrimary: the independent sampler without the others' code */
 __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveBuffers wb, float *__restrict__ film, DeviceCounters *ctr) {
     __shared__ float sfilter[32];
     __shared__ float sred[4 * 4 * 64];         /* splatGroup<.., BLOCK4>: 4 waves x up to 4 passes x 64 words */
@@ -671,7 +684,7 @@ __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveB
     float val[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
     float sx = 0.f, sy = 0.f;
     if (s.active) {
-        const f2 jit = draw2D(bp, s, 0u, 0u, bp.sampler);
+        const f2 jit = draw2D(bp, s, 0u, 0u, INDEP ? KKD_SAMPLER_INDEPENDENT : bp.sampler);
         sx = (float)s.X + jit.x; sy = (float)s.Y + jit.y;
         const float4 acc = wb.accum[i];
         f3 L(acc.x, acc.y, acc.z);
@@ -847,7 +860,8 @@ static inline uint32_t blocksFor(uint64_t n, uint32_t block) { return (uint32_t)
 void launchPrimary(hipStream_t st, bool count, const DScene &sc, const BatchParams &bp, DHit *hits, DeviceCounters *ctr) {
     const bool packet = !ablation(bp, 64u);
     const dim3 grid(blocksFor(bp.count, 256 * (packet ? KKD_PRIMARY_RAYS : 1))), block(256);     /* $KKD_DEBUG bit 64: per-lane walk for primary rays (A/B measurements) */
-#define KKD_LP(C, P, K) hipLaunchKernelGGL((kPrimary<C, P, K, kStackLds, 256>), grid, block, 0, st, sc, bp, hits, ctr)
+#define KKD_LP(C, P, K) do { if (bp.sampler == KKD_SAMPLER_INDEPENDENT) hipLaunchKernelGGL((kPrimary<C, P, K, true, kStackLds, 256>), grid, block, 0, st, sc, bp, hits, ctr); \
+                             else hipLaunchKernelGGL((kPrimary<C, P, K, false, kStackLds, 256>), grid, block, 0, st, sc, bp, hits, ctr); } while (0)
     if (sc.projTris) {
         if (count) { if (packet) KKD_LP(true, true, true); else KKD_LP(true, true, false); }
         else { if (packet) KKD_LP(false, true, true); else KKD_LP(false, true, false); }
@@ -919,6 +933,7 @@ void launchShade(hipStream_t st, const DScene &sc, const BatchParams &bp, const 
     const dim3 grid(blocksFor(bp.count, KKD_SHADE_BLOCK)), block(KKD_SHADE_BLOCK);
     if (bp.sampler == KKD_SAMPLER_LDSAMPLER) hipLaunchKernelGGL(kShade<KKD_SAMPLER_LDSAMPLER>, grid, block, 0, st, sc, bp, wb);
     else if (bp.sampler == KKD_SAMPLER_STRATIFIED) hipLaunchKernelGGL(kShade<KKD_SAMPLER_STRATIFIED>, grid, block, 0, st, sc, bp, wb);
+    else if (bp.sampler == KKD_SAMPLER_HALTON || bp.sampler == KKD_SAMPLER_HALTON_PLAIN) hipLaunchKernelGGL(kShade<KKD_SAMPLER_HALTON>, grid, block, 0, st, sc, bp, wb);
     else hipLaunchKernelGGL(kShade<KKD_SAMPLER_INDEPENDENT>, grid, block, 0, st, sc, bp, wb);
     if (!bp.hideEmitters && sc.envEmitter >= 0) hipLaunchKernelGGL(kEnvMiss, dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, wb);
 }
@@ -956,7 +971,8 @@ void launchAddFilm(hipStream_t st, float *dst, const float *src, uint64_t n) {
 }
 
 void launchResolve(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb, float *film, DeviceCounters *ctr) {
-    hipLaunchKernelGGL(kResolve, dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, wb, film, ctr);
+    if (bp.sampler == KKD_SAMPLER_INDEPENDENT) hipLaunchKernelGGL(kResolve<true>, dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, wb, film, ctr);
+    else hipLaunchKernelGGL(kResolve<false>, dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, wb, film, ctr);
 }
 
 } /* namespace kkd */

@@ -464,6 +464,27 @@ class StratifiedSampler:
         return dict(sampler=abi.SAMPLER_STRATIFIED, sampler_dimension=self.dimension) if self.dimension else dict(sampler=abi.SAMPLER_INDEPENDENT)
 
 
+class HaltonSampler:
+    """Host mirror of the 'halton' plugin (reference src/samplers/halton.cpp:113-130): sampleCount (any number), scramble = -1
+    (Faure permutations, the default) or 0 (none); random permutations (scramble > 0) are drawn from Mitsuba's SFMT and are
+    not available."""
+    PLUGIN_NAME = "halton"
+
+    def __init__(self, props=None, **kw):
+        props = dict(props or {}, **kw)
+        self.sampleCount = int(props.pop("sampleCount", 4))
+        self.scramble = int(props.pop("scramble", -1))
+        if props:
+            raise ValueError("halton: unreferenced properties %s" % sorted(props))
+        if self.sampleCount < 1:
+            raise ValueError("halton: sampleCount must be positive")
+        if self.scramble not in (-1, 0):
+            raise ValueError("halton: scramble must be -1 (Faure permutations) or 0 (none)")
+
+    def render_args(self):
+        return dict(sampler=abi.SAMPLER_HALTON if self.scramble == -1 else abi.SAMPLER_HALTON_PLAIN)
+
+
 class DirectIntegrator:
     """Host mirror of the reference's DirectIntegrator plugin (src/integrators/kk/direct.cpp:15-48).
 
