@@ -197,6 +197,7 @@ static bool kkdRenderOnGpu(Scene *scene, RenderQueue *queue, const RenderJob *jo
         else if (scene->getSampler()->getClass()->getName() == "StratifiedSampler") rp.sampler = KKD_SAMPLER_STRATIFIED;
         /* halton: deterministic; its 'scramble' is not readable from outside the plugin: the default, -1 (Faure permutations) */
         else if (scene->getSampler()->getClass()->getName() == "HaltonSampler") rp.sampler = KKD_SAMPLER_HALTON;
+        else if (scene->getSampler()->getClass()->getName() == "HammersleySampler") rp.sampler = KKD_SAMPLER_HAMMERSLEY;
         else if (scene->getSampler()->getClass()->getName() != "IndependentSampler")
             SLog(EWarn, "kkIntegrator: sampler \"%s\" is not available on the GPU path, using independent samples", scene->getSampler()->getClass()->getName().c_str());
         ref<ImageBlock> block = new ImageBlock(Bitmap::ESpectrumAlphaWeight, film->getCropSize(), NULL);

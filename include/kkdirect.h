@@ -229,7 +229,11 @@ typedef struct kkd_render_params {
      * random permutations, scramble > 0, come from Mitsuba's SFMT and are not offered); dimensions 0 and 1 address the pixel
      * through the 128-pixel tiling of setFilmResolution(res, blocked = true); sample arrays take dimensions 5 ... as in
      * generate().  The prime table ends at dimension 1024, where the reference stops with an error; the path integrator's
-     * deeper vertices draw independent numbers instead. */
+     * deeper vertices draw independent numbers instead;
+     * KKD_SAMPLER_HAMMERSLEY / _HAMMERSLEY_PLAIN = samplers/hammersley.cpp:181-283 on the same functions: dimension 0 is
+     * index / (sampleCount x tile size), dimension d > 0 the radical inverse in the (d - 1)-th prime base; tiles of power-of-two
+     * size up to 128 pixels.  sampleCount = sample_count_total (or spp).  The plugin refuses sample arrays
+     * (hammersley.cpp:296-303), so bsdf_samples and light_samples above 1 are rejected with KKD_ERR_UNSUPPORTED. */
     uint32_t sampler;
     uint32_t sampler_dimension;   /* ldsampler / stratified 'dimension' (0 = their default 4) */
     /* Sampler::getSampleCount() of the whole render when this call renders only the share [sample_first, sample_first + spp) of
@@ -243,6 +247,8 @@ typedef struct kkd_render_params {
 #define KKD_SAMPLER_STRATIFIED  2u
 #define KKD_SAMPLER_HALTON      3u   /* halton plugin with its default scramble = -1: Faure permutations */
 #define KKD_SAMPLER_HALTON_PLAIN 4u  /* halton plugin with scramble = 0: plain radical inverses           */
+#define KKD_SAMPLER_HAMMERSLEY  5u   /* hammersley plugin, scramble = -1 (its default)                    */
+#define KKD_SAMPLER_HAMMERSLEY_PLAIN 6u /* hammersley plugin, scramble = 0                                */
 #define KKD_INTEGRATOR_KK     0u
 #define KKD_INTEGRATOR_DIRECT 1u
 #define KKD_INTEGRATOR_PATH   2u
@@ -369,7 +375,8 @@ int kkd_probe_stratified(uint64_t seed, uint32_t pixel, int kind, uint32_t index
 /* HaltonSampler on a film of res_x x res_y pixels (setFilmResolution(res, true), generate(x, y), halton.cpp:240-384), samples
  * 0 ... count-1 of pixel (x, y) -- kind 0: next2D at running dimension `dim` (out: count x 2; dim 0 = the position inside the
  * pixel), kind 1: next1D at `dim` (out: count), kind 2: requested 2D array `dim` with array_n entries per sample when
- * n_arrays are requested (out: count x array_n x 2).  faure != 0: scramble = -1 (Faure permutations), else scramble = 0. */
+ * n_arrays are requested (out: count x array_n x 2).  faure != 0: scramble = -1 (Faure permutations), else scramble = 0.
+ * n_arrays = 0xFFFFFFFF selects the hammersley plugin (kinds 0 and 1 only) with sampleCount = array_n. */
 int kkd_probe_halton(uint32_t res_x, uint32_t res_y, int32_t x, int32_t y, int faure, int kind, uint32_t dim, uint32_t array_n, uint32_t n_arrays, uint32_t count, float *out);
 /* The Faure permutation of `base` (2 ... 8161) as PermutationStorage::computeFaurePermutations builds it (samplers/faure.cpp:101-131);
  * out: base entries. */

@@ -134,7 +134,9 @@ void ora_stratified(uint64_t seed, uint32_t pixel, int kind, uint32_t index, uin
 }
 /* halton sampler on a resX x resY film, samples 0 ... count-1 of pixel (x, y): kind 0 = next2D at running dimension dim, 1 = next1D, 2 = array dim */
 void ora_halton(uint32_t resX, uint32_t resY, int32_t x, int32_t y, int faure, int kind, uint32_t dim, uint32_t arrayN, uint32_t nArrays, uint32_t count, float *out) {
-    HaltonCfg cfg; cfg.setFilmResolution((int)resX, (int)resY, faure != 0, nArrays);
+    HaltonCfg cfg;
+    if (nArrays == 0xFFFFFFFFu) cfg.setFilmResolutionHammersley((int)resX, (int)resY, faure != 0, arrayN);   /* hammersley with sampleCount = arrayN */
+    else cfg.setFilmResolution((int)resX, (int)resY, faure != 0, nArrays);
     for (uint32_t j = 0; j < count; ++j) {
         SampleStream s(0, 0, j);
         s.useHalton(&cfg, x, y); s.hdim = dim;

@@ -286,6 +286,7 @@ inline uint32_t permuteIndex(uint32_t i, uint32_t l, uint32_t p) {
 struct HaltonCfg {
     std::vector<uint32_t> primes; std::vector<std::vector<uint16_t>> faurePerm;   /* per prime-table entry */
     bool faure = false; uint32_t pow[2] = { 1, 1 }, exp[2] = { 0, 0 }; uint64_t stride = 1, multInverse[2] = { 0, 0 }; uint32_t arrayEnd = 5;
+    bool hammersley = false; uint32_t count = 0; Float factor = 0;                  /* hammersley.cpp: m_sampleCount, m_factor */
     static const HaltonCfg &tables() {
         static const HaltonCfg t = [] {
             HaltonCfg c;
@@ -333,6 +334,22 @@ struct HaltonCfg {
         multInverse[0] = multiplicativeInverse(pow[1], pow[0]); multInverse[1] = multiplicativeInverse(pow[0], pow[1]);
         arrayEnd = 5 + 2 * nArrays;
     }
+    /* HammersleySampler::setFilmResolution(res, blocked = true), hammersley.cpp:181-197 */
+    void setFilmResolutionHammersley(int resX, int resY, bool useFaure, uint32_t sampleCount) {
+        const int res[2] = { resX, resY }; faure = useFaure; hammersley = true; count = sampleCount; arrayEnd = 5;
+        for (int i = 0; i < 2; ++i) {
+            uint32_t v = (uint32_t)res[i]; v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; v++;   /* math::roundToPowerOfTwo */
+            pow[i] = std::min<uint32_t>(128, std::max<uint32_t>(1, v)); exp[i] = 0;
+            while ((1u << exp[i]) < pow[i]) ++exp[i];
+        }
+        factor = (Float)1.0f / (Float)((size_t)sampleCount * (size_t)pow[0] * (size_t)pow[1]);
+        stride = pow[1];
+    }
+    /* nextFloat (hammersley.cpp:242-251 / halton.cpp:343-350) */
+    Float value(uint32_t dim, uint64_t index) const {
+        if (!hammersley) return radicalInverse(dim, index);
+        return dim == 0 ? (Float)index * factor : radicalInverse(dim - 1, index);
+    }
     Float radicalInverse(uint32_t dim, uint64_t index) const {                       /* qmc.cpp:136-165, 198-1228 */
         const HaltonCfg &t = tables();
         const uint32_t base = t.primes[dim];
@@ -349,6 +366,11 @@ struct HaltonCfg {
     static uint32_t tilePos(int p) { return (uint32_t)(((p % 128) + 128) % 128); }   /* pos % MAX_RESOLUTION, made non-negative */
     uint64_t pixelOffset(uint32_t px, uint32_t py) const {                           /* halton.cpp:282-294; Faure(2), Faure(3) = identity */
         if (stride <= 1) return 0;
+        if (hammersley) {                                                            /* hammersley.cpp:218-222 */
+            uint64_t inverse = py, index = 0;
+            for (uint32_t d = exp[1]; d; --d) { index = index * 2 + inverse % 2; inverse /= 2; }
+            return (uint64_t)px * pow[1] * count + index;
+        }
         uint64_t offset = 0; const uint32_t pos[2] = { px, py };
         for (int i = 0; i < 2; ++i) {
             const uint64_t base = i ? 3 : 2; uint64_t inverse = pos[i], index = 0;
@@ -401,7 +423,7 @@ struct SampleStream {
         const uint32_t req = dim1D++;
         if (hal) {                                                                   /* halton.cpp:352-362 */
             if (hdim >= 5 && hdim < hal->arrayEnd) hdim = hal->arrayEnd;
-            if (hdim < 1024) { dim += 1; return hal->radicalInverse(hdim++, haltonIndex(sample)); }
+            if (hdim < 1024) { dim += 1; return hal->value(hdim++, haltonIndex(sample)); }
             hdim += 1; return independent1D();                                       /* past the prime table: the reference stops with an error */
         }
         if (stratRes && req < ldDim) {
@@ -424,7 +446,7 @@ struct SampleStream {
                 dim += 2;
                 const uint64_t index = haltonIndex(sample);
                 const uint32_t d = hdim; hdim += 2;
-                const Float a = hal->radicalInverse(d, index), b = hal->radicalInverse(d + 1, index);
+                const Float a = hal->value(d, index), b = hal->value(d + 1, index);
                 if (d == 0) return V2{ a * (Float)hal->pow[0] - (Float)HaltonCfg::tilePos(hX), b * (Float)hal->pow[1] - (Float)HaltonCfg::tilePos(hY) };
                 return V2{ a, b };
             }

@@ -516,6 +516,8 @@ struct RenderParams { uint32_t spp, nB, nL; bool hideEmitters; uint32_t blockSiz
                       static uint32_t pow2ceil(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
                       HaltonCfg halton;                                                                          /* filled by prepare() */
                       void prepare(int cropW, int cropH) {                                                       /* Integrator::configureSampler, integrator.cpp:37-41 */
+                          if (sampler == KKD_SAMPLER_HAMMERSLEY || sampler == KKD_SAMPLER_HAMMERSLEY_PLAIN)
+                              halton.setFilmResolutionHammersley(cropW, cropH, sampler == KKD_SAMPLER_HAMMERSLEY, total());
                           if (sampler == KKD_SAMPLER_HALTON || sampler == KKD_SAMPLER_HALTON_PLAIN)
                               halton.setFilmResolution(cropW, cropH, sampler == KKD_SAMPLER_HALTON, integrator == KKD_INTEGRATOR_PATH ? 0u : (nB > 1 ? 1u : 0u) + (nL > 1 ? 1u : 0u));
                       }
@@ -525,7 +527,7 @@ struct RenderParams { uint32_t spp, nB, nL; bool hideEmitters; uint32_t blockSiz
                               uint32_t res = 1; while ((uint64_t)res * res < total()) ++res;
                               rng.useStratified(res, samplerDimension ? samplerDimension : 4u);
                           }
-                          if (sampler == KKD_SAMPLER_HALTON || sampler == KKD_SAMPLER_HALTON_PLAIN) rng.useHalton(&halton, X, Y);
+                          if (sampler >= KKD_SAMPLER_HALTON && sampler <= KKD_SAMPLER_HAMMERSLEY_PLAIN) rng.useHalton(&halton, X, Y);
                       } };
 struct Stats { std::atomic<uint64_t> samples{0}, raysClosest{0}, raysShadow{0}, nodes{0}, tris{0}; };
 

@@ -185,7 +185,9 @@ int kkd_probe_stratified(uint64_t seed, uint32_t pixel, int kind, uint32_t index
 int kkd_probe_halton(uint32_t res_x, uint32_t res_y, int32_t x, int32_t y, int faure, int kind, uint32_t dim, uint32_t array_n, uint32_t n_arrays, uint32_t count, float *out) {
     if (!out || !res_x || !res_y || kind < 0 || kind > 2 || (kind == 2 && (!array_n || dim >= n_arrays)) || (kind != 2 && dim + (kind == 0 ? 1u : 0u) >= kHaltonDims)) return KKD_ERR_INVALID;
     static const std::vector<uint32_t> tables = [] { std::vector<uint32_t> t; haltonTables(t); return t; }();
-    HaltonSetup h; haltonSetup((int)res_x, (int)res_y, n_arrays, faure != 0, tables.data(), h);
+    HaltonSetup h;
+    if (n_arrays == 0xFFFFFFFFu) { if (kind == 2 || !array_n) return KKD_ERR_INVALID; hammersleySetup((int)res_x, (int)res_y, array_n, faure != 0, tables.data(), h); }
+    else haltonSetup((int)res_x, (int)res_y, n_arrays, faure != 0, tables.data(), h);
     for (uint32_t j = 0; j < count; ++j) {
         if (kind == 0) { const f2 v = haltonSample2D(h, x, y, j, haltonSkipArrays(h, dim)); out[2 * j] = v.x; out[2 * j + 1] = v.y; }
         else if (kind == 1) out[j] = haltonSample1D(h, x, y, j, haltonSkipArrays(h, dim));
@@ -538,7 +540,9 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     if (rp->spp == 0) return fail(ctx, KKD_ERR_INVALID, "spp must be positive");
     /* kk/direct.cpp:165-166 divides by both counts: zero is not a meaningful configuration */
     if (rp->integrator > KKD_INTEGRATOR_PATH) return fail(ctx, KKD_ERR_INVALID, "unknown integrator");
-    if (rp->sampler > KKD_SAMPLER_HALTON_PLAIN) return fail(ctx, KKD_ERR_INVALID, "unknown sampler");
+    if (rp->sampler > KKD_SAMPLER_HAMMERSLEY_PLAIN) return fail(ctx, KKD_ERR_INVALID, "unknown sampler");
+    if ((rp->sampler == KKD_SAMPLER_HAMMERSLEY || rp->sampler == KKD_SAMPLER_HAMMERSLEY_PLAIN) && rp->integrator != KKD_INTEGRATOR_PATH && (rp->bsdf_samples > 1 || rp->light_samples > 1))
+        return fail(ctx, KKD_ERR_UNSUPPORTED, "request2DArray(): Not supported for the Hammersley QMC sequence!");   /* hammersley.cpp:299-303 */
     if (rp->sample_count_total && (uint64_t)rp->sample_first + rp->spp > rp->sample_count_total)
         return fail(ctx, KKD_ERR_INVALID, "sample_first + spp exceeds sample_count_total");
     if ((rp->sampler == KKD_SAMPLER_LDSAMPLER || rp->sampler == KKD_SAMPLER_STRATIFIED) && (uint64_t)(rp->sample_count_total ? rp->sample_count_total : rp->spp) * 64u > 0x40000000ull)
@@ -668,7 +672,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         uint32_t res = 1; while ((uint64_t)res * res < sampleCountTotal) ++res;
         bp.samplerRes = res; bp.samplerSet = res * res;
     }
-    if (rp->sampler == KKD_SAMPLER_HALTON || rp->sampler == KKD_SAMPLER_HALTON_PLAIN) {
+    if (rp->sampler >= KKD_SAMPLER_HALTON && rp->sampler <= KKD_SAMPLER_HAMMERSLEY_PLAIN) {
         if (!ctx->haltonTables.p) {
             std::vector<uint32_t> words; haltonTables(words);
             const int rcUp = upload(ctx, ctx->haltonTables, words.data(), words.size());
@@ -676,7 +680,8 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
             KKD_HIP(ctx, hipStreamSynchronize(ctx->stream));      /* `words` is read by an asynchronous copy */
         }
         /* Integrator::configureSampler (librender/integrator.cpp:37-41): the crop size, blocked; arrays as kk/direct.cpp:44-47 request them */
-        haltonSetup(W, H, pathMode ? 0u : (nB > 1u ? 1u : 0u) + (nL > 1u ? 1u : 0u), rp->sampler == KKD_SAMPLER_HALTON, (const uint32_t *)ctx->haltonTables.p, bp.halton);
+        if (rp->sampler >= KKD_SAMPLER_HAMMERSLEY) hammersleySetup(W, H, sampleCountTotal, rp->sampler == KKD_SAMPLER_HAMMERSLEY, (const uint32_t *)ctx->haltonTables.p, bp.halton);
+        else haltonSetup(W, H, pathMode ? 0u : (nB > 1u ? 1u : 0u) + (nL > 1u ? 1u : 0u), rp->sampler == KKD_SAMPLER_HALTON, (const uint32_t *)ctx->haltonTables.p, bp.halton);
     }
     bp.integrator = rp->integrator; bp.strictNormals = rp->strict_normals != 0;
     bp.maxDepth = rp->max_depth; bp.rrDepth = rp->rr_depth; bp.depth = 1;

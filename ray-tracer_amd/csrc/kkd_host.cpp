@@ -680,7 +680,20 @@ void haltonSetup(int resX, int resY, uint32_t nArrays, bool faure, const uint32_
     const uint64_t inv[2] = { multiplicativeInverse(h.pow[1], h.pow[0]), multiplicativeInverse(h.pow[0], h.pow[1]) };
     for (int i = 0; i < 2; ++i) h.mul[i] = (stride / h.pow[i]) * inv[i];
     h.arrayEnd = 5u + 2u * nArrays;                                          /* halton.cpp:276-278 */
-    h.tables = tables; h.faure = faure ? 1u : 0u; h.pad = 0;
+    h.tables = tables; h.faure = faure ? 1u : 0u; h.hammersley = 0; h.count = 0; h.factor = 0.f;
+}
+void hammersleySetup(int resX, int resY, uint32_t sampleCount, bool faure, const uint32_t *tables, HaltonSetup &h) {
+    const int res[2] = { resX, resY };
+    for (int i = 0; i < 2; ++i) {
+        uint32_t v = (uint32_t)res[i];                                        /* math::roundToPowerOfTwo */
+        v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; v++;
+        h.pow[i] = std::min(128u, std::max(1u, v)); h.exp[i] = 0;            /* MAX_RESOLUTION, hammersley.cpp:29 */
+        while ((1u << h.exp[i]) < h.pow[i]) ++h.exp[i];
+    }
+    h.stride = h.pow[1]; h.mul[0] = h.mul[1] = 0; h.arrayEnd = 5u;
+    h.count = sampleCount;
+    h.factor = (float)1.0f / (float)((size_t)sampleCount * (size_t)h.pow[0] * (size_t)h.pow[1]);   /* hammersley.cpp:191-192 */
+    h.tables = tables; h.faure = faure ? 1u : 0u; h.hammersley = 1u;
 }
 } /* namespace kkd */
 

@@ -50,6 +50,8 @@ void configureFilter(int type, float radius, const float *param, DFilter &f);
 void haltonTables(std::vector<uint32_t> &words);
 /* HaltonSampler::setFilmResolution(res, blocked = true) + the end of the dimensions reserved to nArrays 2D arrays (halton.cpp:240-279) */
 void haltonSetup(int resX, int resY, uint32_t nArrays, bool faure, const uint32_t *tables, HaltonSetup &h);
+/* HammersleySampler::setFilmResolution(res, blocked = true) for a sampler of sampleCount samples (hammersley.cpp:181-197) */
+void hammersleySetup(int resX, int resY, uint32_t sampleCount, bool faure, const uint32_t *tables, HaltonSetup &h);
 
 uint16_t floatToHalf(float f);
 float halfToFloat(uint16_t h);

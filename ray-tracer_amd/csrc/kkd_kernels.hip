@@ -70,7 +70,7 @@ __device__ __forceinline__ SampleId mapWorkItem(const BatchParams &bp, uint32_t 
  * beyond the sampler's 'dimension' falls back to, ldsampler.cpp:214-228, stratified.cpp:186-187, 201-205), `req` the running
  * number of the 2D (1D) request within the sample, (array, n, e) element e of the sample's n-element slice of requested array
  * `array`.  mode: KKD_SAMPLER_* -- a compile-time constant in kShade, whose register budget has no room for all samplers. */
-__device__ __forceinline__ bool isHalton(uint32_t mode) { return mode == KKD_SAMPLER_HALTON || mode == KKD_SAMPLER_HALTON_PLAIN; }
+__device__ __forceinline__ bool isHalton(uint32_t mode) { return mode >= KKD_SAMPLER_HALTON && mode <= KKD_SAMPLER_HAMMERSLEY_PLAIN; }   /* halton and hammersley: HaltonSetup tells them apart */
 /* halton: one running dimension over all requests of a sample (m_dimension): the kk / direct plugins only make 2D requests, so it is
  * 2 * req; the path plugin's requests sit at fixed dimensions per vertex, the independent stream's (`flat`).  Beyond the prime
  * table (the reference stops with an error there, halton.cpp:356-358) the independent stream takes over. */
@@ -933,7 +933,7 @@ void launchShade(hipStream_t st, const DScene &sc, const BatchParams &bp, const 
     const dim3 grid(blocksFor(bp.count, KKD_SHADE_BLOCK)), block(KKD_SHADE_BLOCK);
     if (bp.sampler == KKD_SAMPLER_LDSAMPLER) hipLaunchKernelGGL(kShade<KKD_SAMPLER_LDSAMPLER>, grid, block, 0, st, sc, bp, wb);
     else if (bp.sampler == KKD_SAMPLER_STRATIFIED) hipLaunchKernelGGL(kShade<KKD_SAMPLER_STRATIFIED>, grid, block, 0, st, sc, bp, wb);
-    else if (bp.sampler == KKD_SAMPLER_HALTON || bp.sampler == KKD_SAMPLER_HALTON_PLAIN) hipLaunchKernelGGL(kShade<KKD_SAMPLER_HALTON>, grid, block, 0, st, sc, bp, wb);
+    else if (bp.sampler >= KKD_SAMPLER_HALTON && bp.sampler <= KKD_SAMPLER_HAMMERSLEY_PLAIN) hipLaunchKernelGGL(kShade<KKD_SAMPLER_HALTON>, grid, block, 0, st, sc, bp, wb);
     else hipLaunchKernelGGL(kShade<KKD_SAMPLER_INDEPENDENT>, grid, block, 0, st, sc, bp, wb);
     if (!bp.hideEmitters && sc.envEmitter >= 0) hipLaunchKernelGGL(kEnvMiss, dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, wb);
 }

@@ -485,6 +485,15 @@ class HaltonSampler:
         return dict(sampler=abi.SAMPLER_HALTON if self.scramble == -1 else abi.SAMPLER_HALTON_PLAIN)
 
 
+class HammersleySampler(HaltonSampler):
+    """Host mirror of the 'hammersley' plugin (reference src/samplers/hammersley.cpp:93-103): sampleCount, scramble = -1 or 0;
+    no sample arrays, so bsdfSamples / lightSamples must be 1 (hammersley.cpp:296-303)."""
+    PLUGIN_NAME = "hammersley"
+
+    def render_args(self):
+        return dict(sampler=abi.SAMPLER_HAMMERSLEY if self.scramble == -1 else abi.SAMPLER_HAMMERSLEY_PLAIN)
+
+
 class DirectIntegrator:
     """Host mirror of the reference's DirectIntegrator plugin (src/integrators/kk/direct.cpp:15-48).
 

@@ -95,6 +95,7 @@ class RenderParams(C.Structure):
 
 INTEGRATOR_KK, INTEGRATOR_DIRECT, INTEGRATOR_PATH = 0, 1, 2
 SAMPLER_INDEPENDENT, SAMPLER_LDSAMPLER, SAMPLER_STRATIFIED, SAMPLER_HALTON, SAMPLER_HALTON_PLAIN = 0, 1, 2, 3, 4
+SAMPLER_HAMMERSLEY, SAMPLER_HAMMERSLEY_PLAIN = 5, 6
 MFILM_MATLAB, MFILM_MATHEMATICA = 0, 1
 
 

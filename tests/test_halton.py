@@ -184,6 +184,86 @@ def test_sample_split_and_edges(gpu):
         b, _ = ctx.render(8, sampler=abi.SAMPLER_HALTON, sample_first=8, sample_count_total=16)
         film, _ = kkdirect.DirectIntegrator().render(sc, ctx=ctx, sampler=kkdirect.HaltonSampler(sampleCount=5))
         with pytest.raises(Exception, match="unknown sampler"):
-            ctx.render(4, sampler=5)
+            ctx.render(4, sampler=9)
     np.testing.assert_allclose(a + b, whole, rtol=1e-5, atol=1e-6)
     assert np.isfinite(film).all() and film[..., 4].sum() > 0
+
+
+# ---- hammersley (reference src/samplers/hammersley.cpp:181-283): the same radical inverses, dimension 0 = index / (samples of a tile) ----
+
+HAM = 0xFFFFFFFF          # kkd_probe_halton: n_arrays value that selects the hammersley plugin, array_n = its sampleCount
+
+
+@pytest.mark.parametrize("res,count", [((200, 150), 16), ((64, 48), 4), ((1920, 1080), 64), ((5, 3), 7)])
+def test_hammersley_samples_land_inside_their_pixel(res, count):
+    """hammersley.cpp:218-222, 268-270: pixel x owns a contiguous block of the tile's indices (dimension 0), the bit-reversed row
+    number in their low digits puts the van der Corput dimension into row y"""
+    rng = np.random.RandomState(4)
+    for _ in range(40):
+        x, y = int(rng.randint(res[0])), int(rng.randint(res[1]))
+        for faure in (False, True):
+            v = _lib(res, (x, y), faure, 0, 0, array_n=count, n_arrays=HAM, count=count)
+            assert (v >= 0).all() and (v < 1).all(), (x, y, v)
+    v = _lib(res, (res[0] // 2, res[1] // 2), False, 0, 0, array_n=count, n_arrays=HAM, count=count)
+    if count & (count - 1) == 0:
+        assert sorted(np.floor(v[:, 0] * count).astype(int)) == list(range(count))      # dimension 0: one sample per column of width 1 / count
+        assert sorted(np.floor(v[:, 1] * count).astype(int)) == list(range(count))      # dimension 1: base 2 in the digits above the row number
+
+
+def test_hammersley_dimensions_are_index_fraction_and_radical_inverses():
+    """a 1 x 1 film: index = sample; dimension 0 = j / count, dimension d = radical inverse in the (d - 1)-th prime base"""
+    n = 32
+    assert np.allclose(_lib((1, 1), (0, 0), False, 1, 0, array_n=n, n_arrays=HAM, count=n), np.arange(n) / n, rtol=3e-7)
+    for d, base in enumerate(PRIMES[:6], start=1):
+        for faure in (False, True):
+            got = _lib((1, 1), (0, 0), faure, 1, d, array_n=n, n_arrays=HAM, count=n)
+            perm = _faure(base) if faure else None
+            np.testing.assert_allclose(got, [float(_radical_inverse(base, j, perm)) for j in range(n)], rtol=3e-7)
+
+
+@pytest.mark.parametrize("args", [((640, 480), (3, 5), False, 0, 0), ((640, 480), (300, 205), True, 0, 2), ((64, 48), (63, 47), True, 1, 7),
+                                  ((3840, 2160), (3839, 2159), True, 0, 1021), ((640, 480), (-2, -1), True, 0, 0)])
+def test_hammersley_library_and_oracle_hand_out_the_same_points(args):
+    res, xy, faure, kind, dim = args
+    a = _lib(res, xy, faure, kind, dim, array_n=64, n_arrays=HAM, count=64)
+    b = kkoracle.halton(res[0], res[1], xy[0], xy[1], faure, kind, dim, 64, HAM, 64)
+    np.testing.assert_array_equal(a, b)
+    assert (a >= 0).all() and (a < 1).all()
+
+
+def test_hammersley_host_mirror():
+    assert kkdirect.HammersleySampler().render_args() == dict(sampler=abi.SAMPLER_HAMMERSLEY)
+    assert kkdirect.HammersleySampler(sampleCount=9, scramble=0).render_args() == dict(sampler=abi.SAMPLER_HAMMERSLEY_PLAIN)
+    with pytest.raises(ValueError):
+        kkdirect.HammersleySampler(scramble=3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sampler", [abi.SAMPLER_HAMMERSLEY, abi.SAMPLER_HAMMERSLEY_PLAIN])
+@pytest.mark.parametrize("integrator,kw", [(abi.INTEGRATOR_KK, {}), (abi.INTEGRATOR_DIRECT, {}), (abi.INTEGRATOR_PATH, dict(max_depth=6, rr_depth=2))])
+def test_hammersley_images_match_the_oracle(gpu, sampler, integrator, kw):
+    sc = _cornell()
+    args = dict(integrator=integrator, sampler=sampler, **kw)
+    want, _ = kkoracle.Oracle(sc).render(spp=16, seed=4, **args)
+    with gpu.Context(device=0, seed=4).upload(sc) as ctx:
+        got, _ = ctx.render(16, **args)
+        if integrator == abi.INTEGRATOR_KK:
+            with pytest.raises(Exception, match="Not supported for the Hammersley"):     # hammersley.cpp:299-303
+                ctx.render(4, light_samples=2, sampler=sampler)
+    assert np.isfinite(got).all()
+    assert helpers.rel_mse(helpers.develop(got), helpers.develop(want)) < 1e-5
+
+
+@pytest.mark.gpu
+def test_hammersley_is_unbiased_and_splits(gpu):
+    sc = _cornell(48, 48)
+    with gpu.Context(device=0, seed=3).upload(sc) as ctx:
+        ref = helpers.develop(ctx.render(1024)[0])
+        ind = helpers.develop(ctx.render(16, sample_first=4096)[0])
+        whole, _ = ctx.render(16, sampler=abi.SAMPLER_HAMMERSLEY)
+        a, _ = ctx.render(8, sampler=abi.SAMPLER_HAMMERSLEY, sample_first=0, sample_count_total=16)
+        b, _ = ctx.render(8, sampler=abi.SAMPLER_HAMMERSLEY, sample_first=8, sample_count_total=16)
+    ham = helpers.develop(whole)
+    np.testing.assert_allclose(a + b, whole, rtol=1e-5, atol=1e-6)
+    assert abs(ham.mean() - ref.mean()) < 0.02 * ref.mean()
+    assert np.sqrt(((ham - ref) ** 2).mean()) < 0.9 * np.sqrt(((ind - ref) ** 2).mean())
