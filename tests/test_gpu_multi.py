@@ -76,3 +76,16 @@ def test_multi_error_behaviour(gpu):
         film, st = m.render(4)
         assert st.samples == 32 * 32 * 4 and film[..., 4].sum() > 0
         assert seen and seen[-1][0] == seen[-1][1] >= st.samples and all(a[0] <= b[0] for a, b in zip(seen, seen[1:]))
+
+
+@pytest.mark.parametrize("sampler", [abi.SAMPLER_LDSAMPLER, abi.SAMPLER_STRATIFIED, abi.SAMPLER_HALTON, abi.SAMPLER_HAMMERSLEY])
+@pytest.mark.parametrize("split", ["tile", "sample"])
+def test_samplers_share_one_point_set_across_ranks(gpu, split, sampler):
+    """sample-split hands every rank a slice of each pixel's one point set (sample_count_total is filled in by kkd_multi_render), tile
+    mode its own pixels: the merged film is the single-context film for every sampler"""
+    sc = scenes.cornell_box(96, 80)
+    with gpu.Context(device=0, seed=6).upload(sc) as ctx:
+        full, _ = ctx.render(16, sampler=sampler)
+    with gpu.MultiContext([0, 0], split=split, seed=6).upload(sc) as m:
+        film, _ = m.render(16, sampler=sampler)
+    np.testing.assert_allclose(film, full, rtol=1e-4, atol=1e-5)
