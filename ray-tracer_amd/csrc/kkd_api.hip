@@ -89,7 +89,7 @@ struct kkd_ctx {
     /* work buffers */
     DevBuf contRecs, contStacks, contCount, pathAlive, pBsdfRays, pBrec, pRefN, pShadowRays, pLrec, pSampleIdx;
     /* first-round step budgets of the round-based traversal; adapted from the share of rays the last batch parked */
-    int capClosest = 28, capAny = 20;
+    int capClosest = 26, capAny = 20;
     DevBuf hits, accum, refN, bsdfRays, bsdfHits, brec0, shadowRays, occluded, lrec, film, counters, apiRays, apiHits;
     std::vector<hipEvent_t> events;
     std::vector<hipEvent_t> doneEvents;   /* one per batch in flight: recorded after the batch's splat (progress reports) */
@@ -650,11 +650,12 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         wb.lrec = (float4 *)laneP(ctx->lrec, S * nL * 16, l);
         wb.sampleIdx = nullptr;
     }
-    /* three rounds: all rays for the adaptive first budget, the parked ones for 32 more steps, what is left of those to the end.
-     * The step counts are heavy-tailed (C4, BSDF rays: 11 % need more than 32 steps, 1.5 % more than 64, 0.3 % more than 128), so
-     * a wave of 64 parked rays again runs several times longer than its mean ray; the middle round packs the tail once more */
+    /* two rounds: all rays for the adaptive first budget, then the parked ones to the end in persistent waves (kTraceTail).  The
+     * step counts are heavy-tailed (C4, BSDF rays: 11 % need more than 32 steps, 1.5 % more than 64, 0.3 % more than 128), so a
+     * wave of 64 parked rays runs several times longer than its mean ray unless its idle lanes are refilled.  ($KKD_TRACE_ROUNDS
+     * > 2 puts plain resume rounds of $KKD_ITER_CAP_LATER steps in between: the layout before the persistent tail.) */
     static const int capLater = [] { const char *e = getenv("KKD_ITER_CAP_LATER"); return envInt(e, 32, 1, 4096); }();
-    static const int rounds = [] { const char *e = getenv("KKD_TRACE_ROUNDS"); return envInt(e, 3, 2, 8); }();
+    static const int rounds = [] { const char *e = getenv("KKD_TRACE_ROUNDS"); return envInt(e, 2, 2, 8); }();
     for (int l = 0; l < nLanes; ++l) { contL[l].iterCapLater = capLater; contL[l].rounds = rounds; }
     DeviceCounters *ctr = (DeviceCounters *)ctx->counters.p;
 
@@ -854,17 +855,18 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     pollProgress(true);
     const DeviceCounters c = sumShards(shards.data(), shards.size());
     {
-        /* Budget control over the whole render: too many parked rays and the second round repeats their set-up for
-         * nothing, too few and the first round idles in its tail.  On C2 and C4 the best fixed budgets park 8-16 % of the traced rays. */
-        auto adapt = [&](int &cap, int used, int envCap, int cls) {
+        /* Budget control over the whole render: too many parked rays and the tail round repeats their set-up for nothing, too
+         * few and the first round idles in its tail.  With the persistent tail round the throughput of C4 is flat while 18-33 % of
+         * the BSDF rays and 28-54 % of the live shadow rays are parked, that of C2 is best at 14 % / 17 % (budgets 26 / 19 on both) */
+        auto adapt = [&](int &cap, int used, int envCap, int cls, double lo, double hi) {
             if (used <= 0 || c.rays[cls] < (1u << 16)) return;
             const double f = (double)c.parked[cls] / (double)c.rays[cls];
-            if (envCap < 0) { if (f > 0.15) cap = std::min(64, cap + 2); else if (f < 0.06) cap = std::max(12, cap - 2); }
+            if (envCap < 0) { if (f > hi) cap = std::min(64, cap + 2); else if (f < lo) cap = std::max(12, cap - 2); }
             static const bool dbg = getenv("KKD_DEBUG_ROUNDS") != nullptr;
             if (dbg) fprintf(stderr, "rounds: class %d budget %d parked %.3f -> budget %d\n", cls, used, f, envCap < 0 ? cap : used);
         };
-        adapt(ctx->capClosest, capClosest, envCapClosest, KKD_RAYS_BSDF);
-        adapt(ctx->capAny, capAny, envCapAny, KKD_RAYS_SHADOW);
+        adapt(ctx->capClosest, capClosest, envCapClosest, KKD_RAYS_BSDF, 0.13, 0.23);
+        adapt(ctx->capAny, capAny, envCapAny, KKD_RAYS_SHADOW, 0.16, 0.34);
     }
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));

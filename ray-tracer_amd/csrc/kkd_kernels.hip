@@ -310,6 +310,66 @@ __global__ void __launch_bounds__(BLOCK, 8) kTraceRound(const Node4 *__restrict_
     }
 }
 
+/* The LAST round, as persistent waves.  A wave draws the records of its shard's queue itself (consume counter = word 2 of the
+ * shard's counter line, zero since the launcher's memset); whenever KKD_TAIL_REFILL of its lanes are done it stores their
+ * results and hands them new records, so that the heavy tail of one ray does not keep 63 lanes idle: the parked rays are
+ * few, long and unlike each other, and a wave of 64 of them runs several times longer than its mean ray (13-16 of 64 lanes
+ * active per instruction in the plain resume kernel).  Every wave leaves: the queue is finite (a wave that finds it empty
+ * stops drawing), each walk is finite, and the outer loop is bounded. */
+#ifndef KKD_TAIL_REFILL
+#define KKD_TAIL_REFILL 24
+#endif
+#ifndef KKD_TAIL_CHUNK
+#define KKD_TAIL_CHUNK 8
+#endif
+template <bool ANY, bool COUNT, int OUT, bool PROJ, int STACK, int BLOCK>
+__global__ void __launch_bounds__(BLOCK, 8) kTraceTail(const Node4 *__restrict__ nodes, const LeafTri *__restrict__ tris, const ProjTri *__restrict__ projTris,
+                                                       const DRay *__restrict__ rays, void *__restrict__ out, DeviceCounters *ctr, int cls, TraceContinuation in) {
+    __shared__ uint32_t sstack[STACK * BLOCK];
+    const uint32_t shard = blockIdx.x % kContShards;
+    const uint32_t nParked = min(in.count[shard * 32u], in.perShard);
+    uint32_t *consume = in.count + shard * 32u + 2u;
+    const void *triTable = PROJ ? (const void *)projTris : (const void *)tris;
+    Walk<ANY, COUNT, PROJ, STACK, BLOCK> w;
+    uint32_t ovf[kStackOverflow];
+    DRay ray; ray.maxt = -1.f; ray.mint = 0.f; ray.ox = ray.oy = ray.oz = 0.f; ray.dx = ray.dy = 0.f; ray.dz = 1.f;
+    w.begin(ray);                       /* finished: maxt < mint */
+    uint32_t myRay = 0; bool have = false, empty = nParked == 0u;
+    uint32_t nn = 0, nt = 0;
+    for (int outer = 1 << 22; outer > 0; --outer) {
+        const unsigned long long idle = __ballot(w.finished());
+        const int nIdle = __popcll(idle);
+        if (!empty && (nIdle >= KKD_TAIL_REFILL || nIdle == 64)) {
+            if (have && w.finished()) { storeTraceResult<OUT>(out, myRay, w.hit, tris); have = false; }
+            uint32_t base = 0;
+            const int leader = __ffsll((long long)idle) - 1;
+            if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(consume, (uint32_t)nIdle);
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+            if (base + (uint32_t)nIdle >= nParked) empty = true;              /* wave-uniform */
+            if (w.finished()) {
+                const uint32_t e = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                if (e < nParked) {
+                    const size_t slot = (size_t)shard * in.perShard + e;
+                    const ContRec r = in.recs[slot];
+                    ray = rays[r.ray]; myRay = r.ray; have = true;
+                    w.begin(ray);
+                    w.cur = r.cur; w.sp = (int)r.sp; w.tmax = r.tmax; w.hit.t = r.t; w.hit.u = r.u; w.hit.v = r.v; w.hit.id = r.id;
+#pragma unroll
+                    for (int q = 0; q < STACK / 4; ++q) {
+                        const uint4 s4 = in.stacks[slot * (STACK / 4) + q];
+                        sstack[(4 * q) * BLOCK + threadIdx.x] = s4.x; sstack[(4 * q + 1) * BLOCK + threadIdx.x] = s4.y;
+                        sstack[(4 * q + 2) * BLOCK + threadIdx.x] = s4.z; sstack[(4 * q + 3) * BLOCK + threadIdx.x] = s4.w;
+                    }
+                }
+            }
+        }
+        if (__ballot(!w.finished()) == 0ull) { if (empty) break; else continue; }
+        w.run(nodes, triTable, sstack, ovf, nn, nt, empty ? (1 << 24) : KKD_TAIL_CHUNK);
+    }
+    if (have) storeTraceResult<OUT>(out, myRay, w.hit, tris);
+    if (ctr && COUNT) countTraversal(nn, nt, counterShard(ctr), cls);
+}
+
 /* ---- camera rays that leave the scene: filtered environment lookup (kk/direct.cpp:55-57 -> envmap.cpp:379-409) -------------
  * Runs after kShade (which has stored alpha and zero radiance for these samples) when the scene has an environment emitter
  * and emitters are not hidden. */
@@ -891,17 +951,21 @@ void launchTrace(hipStream_t st, const DScene &sc, const DRay *rays, uint64_t n,
 
 template <bool ANY, bool COUNT, int OUT, bool PROJ>
 static void launchPhasedT(hipStream_t st, const DScene &sc, const DRay *rays, uint64_t n, void *out, DeviceCounters *ctr, int cls, const TraceContinuation &cont) {
-    /* rounds: [0, cap) on all rays, then cap more steps on what is left, ..., the last round walks to the end.  The two
-     * halves of the continuation buffer alternate as input and output. */
-    TraceContinuation bufs[2] = { cont, cont };
-    const uint32_t half = cont.perShard / 2;
-    bufs[0].perShard = bufs[1].perShard = half;
-    bufs[1].recs = cont.recs + (size_t)kContShards * half; bufs[1].stacks = cont.stacks + (size_t)kContShards * half * (kStackLds / 4);
-    bufs[1].count = cont.count + kContShards * 32;
-    hipMemsetAsync(cont.count, 0, 2 * kContShards * 32 * sizeof(uint32_t), st);   /* both ping-pong counter arrays of this ray kind */
+    /* rounds: [0, cap) on all rays, then (rounds > 2 only) cap more steps on what is left, ...; the last round walks to the end
+     * as persistent waves that draw the parked rays themselves (kTraceTail).  With more than two rounds the two halves of the
+     * continuation buffer alternate as input and output; with two the first round parks into the whole buffer. */
+    static const int tailBlocks = [] { const char *e = getenv("KKD_TAIL_PERSIST"); return e ? atoi(e) : 1; }();   /* blocks per shard; 0: developer switch, plain resume kernel */
     const int rounds = cont.rounds < 2 ? 2 : cont.rounds;
+    TraceContinuation bufs[2] = { cont, cont };
+    if (rounds > 2) {
+        const uint32_t half = cont.perShard / 2;
+        bufs[0].perShard = bufs[1].perShard = half;
+        bufs[1].recs = cont.recs + (size_t)kContShards * half; bufs[1].stacks = cont.stacks + (size_t)kContShards * half * (kStackLds / 4);
+    }
+    bufs[1].count = cont.count + kContShards * 32;
+    hipMemsetAsync(cont.count, 0, 2 * kContShards * 32 * sizeof(uint32_t), st);   /* both counter arrays of this ray kind (fill counters and kTraceTail's consume counters) */
     /* a shard cannot hold more than its share of the rays of this launch */
-    const uint64_t perShardMax = std::min<uint64_t>(half, (n + kContShards - 1) / kContShards + 256);
+    const uint64_t perShardMax = std::min<uint64_t>(bufs[0].perShard, (n + kContShards - 1) / kContShards + 256);
     const dim3 resumeGrid(kContShards * blocksFor(perShardMax, 256)), block(256);
     for (int r = 0; r < rounds; ++r) {
         TraceContinuation in = bufs[(r + 1) & 1], next = bufs[r & 1];
@@ -909,6 +973,9 @@ static void launchPhasedT(hipStream_t st, const DScene &sc, const DRay *rays, ui
         if (r >= 2 && next.iterCap > 0) hipMemsetAsync(next.count, 0, kContShards * 32 * sizeof(uint32_t), st);
         if (r == 0) hipLaunchKernelGGL((kTraceRound<ANY, COUNT, OUT, PROJ, true, kStackLds, 256>), dim3(blocksFor(n, 256)), block, 0, st,
                                        sc.nodes, sc.tris, sc.projTris, rays, n, out, ctr, cls, in, next);
+        else if (next.iterCap == 0 && tailBlocks > 0)
+            hipLaunchKernelGGL((kTraceTail<ANY, COUNT, OUT, PROJ, kStackLds, 256>), dim3(kContShards * (uint32_t)std::min(tailBlocks, 8)), block, 0, st,
+                               sc.nodes, sc.tris, sc.projTris, rays, out, ctr, cls, in);
         else hipLaunchKernelGGL((kTraceRound<ANY, COUNT, OUT, PROJ, false, kStackLds, 256>), resumeGrid, block, 0, st,
                                 sc.nodes, sc.tris, sc.projTris, rays, n, out, ctr, cls, in, next);
     }

@@ -35,6 +35,11 @@ print("RESULT " + json.dumps(out))
 @pytest.mark.parametrize("env", [dict(KKD_ITER_CAP_CLOSEST="3", KKD_ITER_CAP_ANY="2", KKD_ITER_CAP_LATER="2", KKD_TRACE_ROUNDS="5"),
                                  dict(KKD_ITER_CAP_CLOSEST="9", KKD_ITER_CAP_ANY="7", KKD_ITER_CAP_LATER="5", KKD_TRACE_ROUNDS="3"),
                                  dict(KKD_ITER_CAP_CLOSEST="0", KKD_ITER_CAP_ANY="0"),
+                                 # two rounds (the default): nearly every ray goes through the persistent tail round, more than its buffer holds
+                                 dict(KKD_ITER_CAP_CLOSEST="3", KKD_ITER_CAP_ANY="2"),
+                                 dict(KKD_ITER_CAP_CLOSEST="6", KKD_ITER_CAP_ANY="4", KKD_TAIL_PERSIST="4"),
+                                 dict(KKD_TAIL_PERSIST="0", KKD_TRACE_ROUNDS="3"),                      # the plain resume rounds
+                                 dict(KKD_TAIL_PERSIST="0", KKD_ITER_CAP_CLOSEST="4", KKD_ITER_CAP_ANY="3"),
                                  # stray settings must not change a result: the release build ignores the ablation bits of
                                  # $KKD_DEBUG (they exist only with -DKKD_ABLATION) and clamps the performance knobs
                                  dict(KKD_DEBUG="7", KKD_STREAMS="-3", KKD_TRACE_ROUNDS="-1", KKD_ITER_CAP_LATER="-5"),
