@@ -21,8 +21,8 @@ def stage_of(name):
     if "kPrimary" in name: return "primary"
     if "kShade" in name: return "shade"
     if "kResolve" in name: return "resolve"
-    if "kTrace<false" in name or "kTraceRound<false" in name: return "bsdf"
-    if "kTrace<true" in name or "kTraceRound<true" in name: return "shadow"
+    if "kTrace<false" in name or "kTraceRound<false" in name or "kTraceTail<false" in name: return "bsdf"
+    if "kTrace<true" in name or "kTraceRound<true" in name or "kTraceTail<true" in name: return "shadow"
     return None
 
 

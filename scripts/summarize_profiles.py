@@ -14,12 +14,12 @@ def stage_of(name):
     if "kPrimary" in name: return "primary"
     if "kShade" in name: return "shade"
     if "kResolve" in name: return "resolve"
-    if "kTrace<false" in name or "kTraceRound<false" in name: return "bsdf"
-    if "kTrace<true" in name or "kTraceRound<true" in name: return "shadow"
+    if "kTrace<false" in name or "kTraceRound<false" in name or "kTraceTail<false" in name: return "bsdf"
+    if "kTrace<true" in name or "kTraceRound<true" in name or "kTraceTail<true" in name: return "shadow"
     return None
 
 def counting(name):   # counting variants (COUNT template argument true) are not part of the timed loop
-    return "kPrimary<true" in name or "kTrace<false, true" in name or "kTrace<true, true" in name or "kTraceRound<false, true" in name or "kTraceRound<true, true" in name
+    return "kPrimary<true" in name or "kTrace<false, true" in name or "kTrace<true, true" in name or "kTraceRound<false, true" in name or "kTraceRound<true, true" in name or "kTraceTail<false, true" in name or "kTraceTail<true, true" in name
 
 shutil.copy(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0], os.path.join(dst, "%s_bench_c2_kernel_stats.csv" % tag))
 shutil.copy(os.path.join(src, "bench_under_trace.json"), os.path.join(dst, "%s_bench_c2_under_rocprof.json" % tag))
