@@ -262,8 +262,8 @@ def measure_roofline(ctx, scene, args, kw, n_b, n_l, spp, film, stats, elapsed, 
     pmc = None if args.scale != 1.0 else load_pmc(args.workload, name, samples_per_batch)    # another resolution is another workload
     traffic = None if pmc is None else pmc["hbm_bytes_per_launch"]
     per_batch = launches / max(1, stage_n[1])
-    kernel_note = {"bsdf": "bsdf = kTraceRound<closest> (%d rounds = %d launches per batch of rays, averaged)" % (per_batch, per_batch),
-                   "shadow": "shadow = kTraceRound<any> (%d rounds = %d launches per batch of rays, averaged)" % (per_batch, per_batch)}
+    kernel_note = {"bsdf": "bsdf = kTraceRound<closest> + kTraceTail<closest> (%d rounds = %d launches per batch of rays, averaged)" % (per_batch, per_batch),
+                   "shadow": "shadow = kTraceRound<any> + kTraceTail<any> (%d rounds = %d launches per batch of rays, averaged)" % (per_batch, per_batch)}
     valu = None if pmc is None or not pmc.get("valu_insts_per_launch") else pmc["valu_insts_per_launch"] / avg_launch_s / VALU_ISSUE_PEAK_PER_S
     hbm_frac = achieved / HBM_PEAK_GBS
     r = {"bound": "hbm", "kernel": kernel_note.get(name, name), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
