@@ -569,9 +569,10 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     const uint32_t nbx = (W + 2 * edge + bs - 1) / bs, nby = (H + 2 * edge + bs - 1) / bs, nTiles = nbx * nby;
     if (nbx > 0xffffu || nby > 0xffffu) return fail(ctx, KKD_ERR_UNSUPPORTED, "more than 65535 tiles along one axis");
     const uint32_t nTilesMine = tileIndex < nTiles ? (nTiles - tileIndex + tileCount - 1) / tileCount : 0;
+    if (tileCount <= 1 || nTilesMine == 0) ctx->tileListHost.clear();      /* the list describes THIS render: none of an earlier one survives */
     if (tileCount > 1 && nTilesMine > 0) {
         const uint32_t key[4] = { nbx, nby, tileIndex, tileCount };
-        if (std::memcmp(key, ctx->tileKey, sizeof(key)) != 0 || !ctx->tileList.p) {
+        if (std::memcmp(key, ctx->tileKey, sizeof(key)) != 0 || !ctx->tileList.p || ctx->tileListHost.size() != nTilesMine) {
             tilesOfRank(nbx, nby, tileIndex, tileCount, ctx->tileListHost, true);      /* device copy: [my tiles | rank of every tile] */
             int rcUp = upload(ctx, ctx->tileList, ctx->tileListHost.data(), ctx->tileListHost.size());
             ctx->tileListHost.resize(nTilesMine);
@@ -1080,9 +1081,11 @@ static int multiRender(kkd_multi *m, const kkd_render_params *rp, float *rootDev
         rcs[r] = renderImpl(x, &prm[r], r == 0 ? rootDevFilm : nullptr, &st[r]);      /* ranks > 0 render into their own film buffer */
         if (rcs[r] != KKD_OK || r == 0 || !gather) return;
         /* tile mode: pack this rank's tiles (with borders) and send them to the root device in one copy */
-        const uint32_t nt = (uint32_t)x->tileListHost.size();
-        nTilesOf[r] = nt;
+        /* the rank's tile count is a function of the grid alone (nTilesOf, filled in with the staging buffers below): never
+         * what an earlier render on this context left in its list */
+        const uint32_t nt = nTilesOf[r];
         if (nt == 0) return;
+        if (x->tileListHost.size() != nt) { x->err = "tile gather: the context's tile list does not match the grid"; rcs[r] = KKD_ERR_DEVICE; return; }
         hipError_t e = m->packed[r].ensure(nt * perTile * sizeof(float));
         TileGrid mine = grid; mine.rankOf = (const uint32_t *)x->tileList.p + nt; mine.myRank = prm[r].tile_index;
         if (e == hipSuccess) { launchPackTiles(x->stream, (const float *)x->film.p, (float *)m->packed[r].p, (const uint32_t *)x->tileList.p, nt, mine); e = hipGetLastError(); }
@@ -1100,6 +1103,7 @@ static int multiRender(kkd_multi *m, const kkd_render_params *rp, float *rootDev
         std::vector<uint32_t> list;
         for (uint32_t r = 1; r < n; ++r) {
             tilesOfRank(grid.nbx, nby, prm[r].tile_index, prm[r].tile_count, list);
+            nTilesOf[r] = (uint32_t)list.size();
             hipError_t e = m->staging[r].ensure(std::max<size_t>(16, list.size() * perTile * sizeof(float)));
             if (e == hipSuccess) e = m->rankTiles[r].ensure(std::max<size_t>(16, list.size() * sizeof(uint32_t)));
             if (e == hipSuccess && !list.empty()) e = hipMemcpy(m->rankTiles[r].p, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice);

@@ -130,8 +130,8 @@ struct Builder {
 };
 
 /* Subtrees of at most deferBelow primitives are not collapsed by the caller's walk: it records them (in DFS order) and they are
- * collapsed side by side into vectors of their own, which are then appended -- nodes after the top of the tree, triangles in
- * the same leaf order as one serial walk gives. */
+ * collapsed side by side into vectors of their own, which are then appended -- nodes after the top of the tree, triangles after
+ * the top walk's own leaves. */
 struct Deferred { uint32_t root; uint32_t parent; int slot; int depth, stackAbove; };
 struct Collapser {
     const Builder &b; const float *pos; const uint32_t *idx; const uint32_t *shapeOfPrim;
@@ -255,7 +255,10 @@ bool BVH4::build(const float *positions, const uint32_t *indices, uint64_t nTris
         info.maxDepth = 1; info.maxStack = 0;
     } else {
         std::vector<Deferred> deferred;
-        if (nThreads > 1 && nTris > 262144) { c.deferBelow = (uint32_t)std::max<uint64_t>(65536, nTris / (8 * nThreads)); c.deferred = &deferred; }
+        /* the deferral threshold is a function of the triangle count alone, so that the node and triangle order (hence every
+         * slot number) is the same on every host, whatever its core count: the top walk emits its inline leaves first and the
+         * deferred subtrees' triangles are appended after them, which is NOT the leaf order of one serial walk */
+        if (nTris > 262144) { c.deferBelow = (uint32_t)std::max<uint64_t>(65536, nTris / 128); c.deferred = &deferred; }
         c.emit(root, 0, 0);
         if (!deferred.empty()) {
             /* the deferred subtrees, collapsed side by side into their own vectors (local node indices and leaf slots) */
@@ -306,6 +309,7 @@ void makeProjTris(const std::vector<LeafTri> &tris, std::vector<ProjTri> &out) {
     for (size_t i = 0; i < tris.size(); ++i) {
         const LeafTri &t = tris[i];
         ProjTri r; std::memset(&r, 0, sizeof(r));
+        r.prim = t.prim;
         const volatile float A[3] = { t.v0x, t.v0y, t.v0z };
         const float b[3] = { t.v2x - t.v0x, t.v2y - t.v0y, t.v2z - t.v0z };   /* C - A */
         const float c[3] = { t.v1x - t.v0x, t.v1y - t.v0y, t.v1z - t.v0z };   /* B - A */

@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(256) kProjTris(const LeafTri *__restrict__ tri
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const LeafTri t = tris[i];
-    ProjTri r; r.n_u = r.n_v = r.n_d = 0.f; r.k = 0u; r.a_u = r.a_v = r.b_nu = r.b_nv = 0.f; r.c_nu = r.c_nv = 0.f; r.pad[0] = r.pad[1] = 0u;
+    ProjTri r; r.n_u = r.n_v = r.n_d = 0.f; r.k = 0u; r.a_u = r.a_v = r.b_nu = r.b_nv = 0.f; r.c_nu = r.c_nv = 0.f; r.prim = t.prim; r.pad = 0u;
     const float A[3] = { t.v0x, t.v0y, t.v0z };
     const float b[3] = { __fsub_rn(t.v2x, t.v0x), __fsub_rn(t.v2y, t.v0y), __fsub_rn(t.v2z, t.v0z) };
     const float c[3] = { __fsub_rn(t.v1x, t.v0x), __fsub_rn(t.v1y, t.v0y), __fsub_rn(t.v1z, t.v0z) };

@@ -58,8 +58,9 @@ void launchPrimary(hipStream_t st, bool count, const DScene &sc, const BatchPara
 /* outMode: 0 = DHit with LeafTri slot, 1 = DHit with global primitive id, 2 = uint32 occlusion flags (anyHit only) */
 /* rayClass: which DeviceCounters slot the launch accounts to */
 void launchTrace(hipStream_t st, const DScene &sc, const DRay *rays, uint64_t n, bool anyHit, bool count, int outMode, void *out, DeviceCounters *ctr, int rayClass);
-/* A ray parked by kTraceFirst after its iteration budget: everything Walk needs to go on (32 bytes + 16 stack words). */
-struct alignas(16) ContRec { uint32_t ray, cur, sp; float tmax, t, u, v; uint32_t id; };
+/* A ray parked by kTraceRound after its iteration budget: everything Walk needs to go on (32 bytes + 16 stack words; the best
+ * hit's distance is tmax). */
+struct alignas(16) ContRec { uint32_t ray, cur, sp; float tmax; uint32_t pend; float u, v; uint32_t id; };
 /* stacks: 16 words (= kStackLds, kkd_trace.h) per record */
 /* The buffer is cut into kContShards regions of perShard records, each with its own fill counter on its own 128-byte
  * line (count[shard * 32]): one counter for all waves would serialise at ~88 M atomics/s, like the ray counters did. */

@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(BLOCK, 8) kTraceRound(const Node4 *__restrict_
                                                         TraceContinuation in, TraceContinuation next) {
     __shared__ uint32_t sstack[STACK * BLOCK];
     DRay ray; ray.maxt = -1.f; ray.mint = 0.f; ray.ox = ray.oy = ray.oz = 0.f; ray.dx = ray.dy = 0.f; ray.dz = 1.f;
-    ContRec r; r.ray = 0; r.cur = kTraversalDone; r.sp = 0; r.tmax = -1.f; r.t = kInf; r.u = r.v = 0.f; r.id = kNoHit;
+    ContRec r; r.ray = 0; r.cur = kTraversalDone; r.sp = 0; r.tmax = -1.f; r.pend = 0u; r.u = r.v = 0.f; r.id = kNoHit;
     bool mine;                      /* this lane holds a ray */
     size_t inSlot = 0;
     if (FIRST && !ANY) {
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(BLOCK, 8) kTraceRound(const Node4 *__restrict_
     w.begin(ray);
     const bool traced = FIRST && mine && !w.finished();
     if (!FIRST) {
-        w.cur = r.cur; w.sp = (int)r.sp; w.tmax = r.tmax; w.hit.t = r.t; w.hit.u = r.u; w.hit.v = r.v; w.hit.id = r.id;
+        w.resume(r.cur, r.pend, (int)r.sp, r.tmax, r.u, r.v, r.id, (mine && r.id != kNoHit) ? tris[r.id].prim : 0u);
         if (mine) {
 #pragma unroll
             for (int q = 0; q < STACK / 4; ++q) {
@@ -283,21 +283,26 @@ __global__ void __launch_bounds__(BLOCK, 8) kTraceRound(const Node4 *__restrict_
                 const int leader = __ffsll((long long)m) - 1;
                 if ((int)(threadIdx.x & 63) == leader) {
                     base = atomicAdd(next.count + shard * 32u, (uint32_t)__popcll(m));
-                    if (FIRST && ctr) atomicAdd(&counterShard(ctr)->parked[cls], (unsigned long long)__popcll(m));
                 }
                 base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
             }
             const uint32_t rank = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             parked = want && rank < next.perShard;              /* a full shard: walk on instead */
+            if (FIRST && ctr) {
+                /* what steers the budgets is the rays that WERE parked: not the lanes a full shard turned away, nor those whose
+                 * stack had spilled */
+                const unsigned long long pm = __ballot(parked);
+                if (pm != 0ull && (int)(threadIdx.x & 63) == __ffsll((long long)pm) - 1) atomicAdd(&counterShard(ctr)->parked[cls], (unsigned long long)__popcll(pm));
+            }
             const size_t slot = (size_t)shard * next.perShard + rank;
             if (parked) {
-                ContRec o; o.ray = r.ray; o.cur = w.cur; o.sp = (uint32_t)w.sp; o.tmax = w.tmax; o.t = w.hit.t; o.u = w.hit.u; o.v = w.hit.v; o.id = w.hit.id;
+                ContRec o; o.ray = r.ray; o.cur = w.cur; o.sp = (uint32_t)w.sp; o.tmax = w.tmax; o.pend = w.pend; o.u = w.hit.u; o.v = w.hit.v; o.id = w.hit.id;
                 next.recs[slot] = o;
 #pragma unroll
                 for (int q = 0; q < STACK / 4; ++q)
                     next.stacks[slot * (STACK / 4) + q] = make_uint4(sstack[(4 * q) * BLOCK + threadIdx.x], sstack[(4 * q + 1) * BLOCK + threadIdx.x],
                                                                      sstack[(4 * q + 2) * BLOCK + threadIdx.x], sstack[(4 * q + 3) * BLOCK + threadIdx.x]);
-                w.cur = kTraversalDone;
+                w.stop();
             }
         }
     }
@@ -353,7 +358,7 @@ __global__ void __launch_bounds__(BLOCK, 8) kTraceTail(const Node4 *__restrict__
                     const ContRec r = in.recs[slot];
                     ray = rays[r.ray]; myRay = r.ray; have = true;
                     w.begin(ray);
-                    w.cur = r.cur; w.sp = (int)r.sp; w.tmax = r.tmax; w.hit.t = r.t; w.hit.u = r.u; w.hit.v = r.v; w.hit.id = r.id;
+                    w.resume(r.cur, r.pend, (int)r.sp, r.tmax, r.u, r.v, r.id, r.id != kNoHit ? tris[r.id].prim : 0u);
 #pragma unroll
                     for (int q = 0; q < STACK / 4; ++q) {
                         const uint4 s4 = in.stacks[slot * (STACK / 4) + q];

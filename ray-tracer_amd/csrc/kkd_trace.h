@@ -113,14 +113,31 @@ template <bool ANY> __device__ __forceinline__ float adaptiveMinT(float mint, fl
  * at most iterCap steps (all state -- current reference, stack pointer, clipped interval, best hit -- stays in the
  * object and in the lane's stack), so a kernel can stop a wave whose last few lanes are still walking, park those lanes
  * in memory and let a later, densely packed launch finish them (kTraceFirst / kTraceResume). */
+/* A lane that reaches a leaf does not spend an iteration on it: the leaf becomes its PENDING leaf, the lane takes the next
+ * entry of its stack at once, and in the following iterations it takes a node step AND tests one triangle of the pending leaf
+ * (round 3: C4 one-lane BSDF / shadow stage 460 / 326 -> 449 / 313 ms).  A lane that reaches a second leaf while one is pending
+ * waits for the triangle step.
+ * KKD_TRI_GATE > 0 (developer switch): "speculative" traversal after Aila & Laine 2009 -- the triangle step of an iteration
+ * is issued only when at least that many lanes hold a pending leaf (or KKD_TRI_GATE_BLOCKED lanes are blocked at a second
+ * leaf, or no lane can take a node step), so that its ~90 instructions run for 20-30 lanes instead of ~10.  Built and
+ * measured in round 3 (C4 one-lane BSDF / shadow ms): gate 12 / blocked 6: 459 / 317; 20 / 4: 457 / 316; 20 / 8: 467 / 321;
+ * 28 / 12: 490 / 332, against 449 / 313 without a gate: a wave runs as long as its longest ray, every iteration that ray waits
+ * for the gate lengthens the wave, and that costs more than the triangle steps saved.  Default 0. */
+#ifndef KKD_TRI_GATE
+#define KKD_TRI_GATE 0
+#endif
+#ifndef KKD_TRI_GATE_BLOCKED
+#define KKD_TRI_GATE_BLOCKED 8
+#endif
 template <bool ANY, bool COUNT, bool PROJ, int STACK, int BLOCK>
 struct Walk {
     /* (the private part of the stack, kStackOverflow words, is the caller's array: an array member would pin the whole
      * object in scratch memory) */
-    DHit hit; float ox, oy, oz, dx, dy, dz, tmin, tmax, idx, idy, idz; WoopRay wr; uint32_t cur; int sp;
+    DHit hit; uint32_t hprim;                        /* hprim: primitive id of the best hit (equal-distance ties) */
+    float ox, oy, oz, dx, dy, dz, tmin, tmax, idx, idy, idz; WoopRay wr; uint32_t cur, pend; int sp;
 
     __device__ __forceinline__ void begin(const DRay &ray) {
-        hit.t = kInf; hit.u = 0.f; hit.v = 0.f; hit.id = kNoHit;
+        hit.t = kInf; hit.u = 0.f; hit.v = 0.f; hit.id = kNoHit; hprim = 0u;
         ox = ray.ox; oy = ray.oy; oz = ray.oz; dx = ray.dx; dy = ray.dy; dz = ray.dz;
         tmin = adaptiveMinT<ANY>(ray.mint, ox, oy, oz);
         tmax = ray.maxt;
@@ -130,11 +147,18 @@ struct Walk {
         idx = fabsf(dx) < kTiny ? copysignf(kBig, dx) : 1.0f / dx;
         idy = fabsf(dy) < kTiny ? copysignf(kBig, dy) : 1.0f / dy;
         idz = fabsf(dz) < kTiny ? copysignf(kBig, dz) : 1.0f / dz;
-        wr.init(dx, dy, dz);
-        sp = 0;
+        if (!PROJ) wr.init(dx, dy, dz);
+        sp = 0; pend = 0u;
         cur = (tmax > tmin) ? 0u : kTraversalDone;      /* cur: inner node index | leaf reference (kLeafBit) | kTraversalDone */
     }
-    __device__ __forceinline__ bool finished() const { return cur == kTraversalDone; }
+    /* pend: the leaf whose triangles are still to be tested (a leaf reference, 0 = none) */
+    __device__ __forceinline__ bool finished() const { return cur == kTraversalDone && pend == 0u; }
+    __device__ __forceinline__ void stop() { cur = kTraversalDone; pend = 0u; }
+    /* the state a parked ray was left in (its stack words are the caller's to restore); the best hit's distance is tmax */
+    __device__ __forceinline__ void resume(uint32_t cur_, uint32_t pend_, int sp_, float tmax_, float u, float v, uint32_t id, uint32_t prim) {
+        cur = cur_; pend = pend_; sp = sp_; tmax = tmax_;
+        hit.t = id != kNoHit ? tmax_ : kInf; hit.u = u; hit.v = v; hit.id = id; hprim = prim;
+    }
 
     __device__ __forceinline__ void run(const Node4 *__restrict__ nodes, const void *__restrict__ tris, uint32_t *sstack, uint32_t *ovf,
                                         uint32_t &nNodes, uint32_t &nTris, int iterCap) {
@@ -142,21 +166,18 @@ struct Walk {
         const uint4 *nodes4 = reinterpret_cast<const uint4 *>(nodes);
         const float4 *tris4 = reinterpret_cast<const float4 *>(tris);
         const int tid = threadIdx.x;
-        DRay ray; ray.dx = dx; ray.dy = dy; ray.dz = dz;   /* projIntersect reads the direction */
 #define KKD_PUSH(V) { if (sp < STACK) sstack[sp * BLOCK + tid] = (V); else ovf[sp - STACK] = (V); ++sp; }
 /* the LDS read is unconditional and the private read a separate, rarely taken branch: one select between the two
  * pointers would turn every pop into a flat load, which goes the long way round through the texture addresser */
 #define KKD_POP() { if (sp == 0) cur = kTraversalDone; else { --sp; cur = sstack[(sp < STACK ? sp : STACK - 1) * BLOCK + tid]; \
                     if (sp >= STACK) cur = ovf[sp - STACK]; } }
-        /* One step per iteration and lane: a node visit or ONE triangle test, so a lane at a leaf and a lane at a node both
-         * make progress and the iteration costs one node visit plus one triangle test, not the longest leaf of the wave.
-         * Every wave leaves this loop: the walk is finite on a tree, and the step bound ends it on a malformed one. */
+        /* One step per iteration and lane: a node visit, and -- when the wave takes a triangle step -- ONE triangle test of the
+         * lane's pending leaf, so the iteration costs at most one node visit plus one triangle test, not the longest leaf of the
+         * wave.  Every wave leaves this loop: the walk is finite on a tree, a wave in which no lane can take a node step takes
+         * triangle steps until a lane can, and the step bound ends it on a malformed tree. */
         for (int guard = iterCap; guard > 0; --guard) {
             const bool atNode = !(cur & kLeafBit);
-            const bool atLeaf = !atNode && cur != kTraversalDone;
-            const unsigned long long leafLanes = __ballot(atLeaf);
-            const bool anyNode = __ballot(atNode) != 0ull;
-            if (!anyNode && leafLanes == 0ull) break;
+            if (__ballot(atNode || pend != 0u || cur != kTraversalDone) == 0ull) break;
             if (atNode) {
                 if (COUNT) ++nNodes;
                 const uint4 *n = nodes4 + (size_t)cur * 4;
@@ -214,29 +235,34 @@ struct Walk {
                 } else KKD_POP()
                 }
             }
+            /* a lane at a leaf with nothing pending makes the leaf its pending one and takes the next entry of its stack: it
+             * walks on while the leaf waits for the wave's next triangle step */
+            if ((cur & kLeafBit) && cur != kTraversalDone && pend == 0u) { pend = cur; KKD_POP() }
             {
-                /* a lane whose node step just entered a leaf (nearest child, or popped) tests its first triangle in this same
-                 * iteration: the triangle code is issued anyway, so the step is free (C4 2759 -> 2862, C2 3227 -> 3293 Msamples/s).
-                 * Two node steps per iteration were measured as well: C4 2721, C2 3239. */
-                if ((cur & kLeafBit) && cur != kTraversalDone) {
-                    const uint32_t slot = cur & kLeafStartMask;
+                const unsigned long long pendLanes = __ballot(pend != 0u);
+                const unsigned long long blocked = __ballot((cur & kLeafBit) && cur != kTraversalDone);       /* a second leaf while one is pending */
+                const bool canWalk = __ballot(!(cur & kLeafBit)) != 0ull;
+                if (pendLanes != 0ull && (KKD_TRI_GATE == 0 || !canWalk || __popcll(pendLanes) >= KKD_TRI_GATE || __popcll(blocked) >= KKD_TRI_GATE_BLOCKED)) {
+                if (pend != 0u) {
+                    const uint32_t slot = pend & kLeafStartMask;
                     if (COUNT) ++nTris;
                     const float4 *tp = tris4 + 3u * slot;   /* 32-bit shift-add, not a quarter-rate 64-bit multiply */
                     const float4 a = tp[0], b = tp[1], c = tp[2];
                     float t, u, v;
-                    bool done = false;
-                    /* of two triangles hit at the same distance the one in the lower slot is reported, whatever the order in which
-                     * the walk reaches them: the packet walk's order depends on the other rays of the wave, and a render cut
-                     * into tiles or sample ranges groups the rays differently (coplanar emitters made 4 pixels of C3 differ) */
-                    if ((PROJ ? projIntersect(ox, oy, oz, ray.dx, ray.dy, ray.dz, a, b, c, tmin, tmax, t, u, v)
+                    /* of two triangles hit at the same distance the one with the lower primitive id is reported, whatever the order
+                     * in which the walk reaches them: the packet walk's order depends on the other rays of the wave, a render cut
+                     * into tiles or sample ranges groups the rays differently (coplanar emitters made 4 pixels of C3 differ), and
+                     * slot numbers depend on which builder made the tree */
+                    const uint32_t prim = PROJ ? __float_as_uint(c.z) : __float_as_uint(a.w);
+                    if ((PROJ ? projIntersect(ox, oy, oz, dx, dy, dz, a, b, c, tmin, tmax, t, u, v)
                               : woopIntersect(wr, ox, oy, oz, a, b, c, tmin, tmax, t, u, v))
-                        && (ANY || t < tmax || hit.id == kNoHit || slot < hit.id)) {
-                        tmax = t; hit.t = t; hit.u = u; hit.v = v; hit.id = slot;
-                        done = ANY;
+                        && (ANY || t < tmax || hit.id == kNoHit || prim < hprim)) {
+                        tmax = t; hit.t = t; hit.u = u; hit.v = v; hit.id = slot; hprim = prim;
+                        if (ANY) stop();
                     }
-                    if (done) cur = kTraversalDone;
-                    else if (cur & (7u << 28)) cur = cur - (1u << 28) + 1u;   /* next triangle of this leaf */
-                    else KKD_POP()
+                    if (pend & (7u << 28)) pend = pend - (1u << 28) + 1u;   /* next triangle of this leaf */
+                    else pend = 0u;
+                }
                 }
             }
         }
@@ -281,6 +307,9 @@ __device__ __forceinline__ void packetWalk(const WideNode *__restrict__ wnodes, 
                                            uint32_t *wstack, DHit *hit, uint32_t &nNodes, uint32_t &nTris) {
     int sp = 0;
     uint32_t cur = 0;
+    uint32_t hprim[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) hprim[r] = 0u;
     /* every wave leaves this loop: each iteration pops or descends in a finite tree; the step bound ends a malformed one */
     for (int guard = 1 << 24; guard > 0; --guard) {
         cur = __builtin_amdgcn_readfirstlane(cur);
@@ -333,13 +362,14 @@ __device__ __forceinline__ void packetWalk(const WideNode *__restrict__ wnodes, 
             for (uint32_t i = 0; i < cnt; ++i) {
                 const float4 *tp = tris4 + 3u * (start + i);
                 const float4 a = tp[0], b = tp[1], c = tp[2];
+                const uint32_t prim = PROJ ? __float_as_uint(c.z) : __float_as_uint(a.w);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     float t, u, v;
                     if ((PROJ ? projIntersect(ray[r].ox, ray[r].oy, ray[r].oz, ray[r].dx, ray[r].dy, ray[r].dz, a, b, c, tmin[r], tmax[r], t, u, v)
                               : woopIntersect(wr[r], ray[r].ox, ray[r].oy, ray[r].oz, a, b, c, tmin[r], tmax[r], t, u, v))
-                        && (t < tmax[r] || hit[r].id == kNoHit || start + i < hit[r].id)) {      /* equal distances: the lower slot, as in Walk::run */
-                        tmax[r] = t; hit[r].t = t; hit[r].u = u; hit[r].v = v; hit[r].id = start + i;
+                        && (t < tmax[r] || hit[r].id == kNoHit || prim < hprim[r])) {      /* equal distances: the lower primitive id, as in Walk::run */
+                        tmax[r] = t; hit[r].t = t; hit[r].u = u; hit[r].v = v; hit[r].id = start + i; hprim[r] = prim;
                     }
                 }
             }

@@ -61,7 +61,7 @@ static constexpr uint32_t kHitNotEmitter = 0x40000000u;
 struct alignas(16) ProjTri {
     float n_u, n_v, n_d; uint32_t k;
     float a_u, a_v, b_nu, b_nv;
-    float c_nu, c_nv; uint32_t pad[2];
+    float c_nu, c_nv; uint32_t prim /* = LeafTri::prim: equal-distance ties go to the lower primitive id */, pad;
 };
 
 /* ---- BSDF::EBSDFType bits used on this path (names follow the reference's bsdf.h) ---- */
