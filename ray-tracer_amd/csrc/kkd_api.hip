@@ -264,6 +264,8 @@ static int buildHostScene(kkd_ctx *ctx, const kkd_scene_desc *sd, HostScene &hs)
     if (gpuBuild) return KKD_OK;          /* the tree is built by uploadHostScene, on the device */
     /* the kernels index their stack without a bound check: the builder's worst-case occupancy must fit */
     if (hs.bvh.info.maxStack > kMaxTraversalStack) return fail(ctx, KKD_ERR_UNSUPPORTED, "acceleration structure deeper than the traversal stack");
+    if (hs.bvh.nodes.size() * sizeof(Node4) > kMaxAccelBytes || hs.bvh.tris.size() * sizeof(LeafTri) > kMaxAccelBytes)
+        return fail(ctx, KKD_ERR_UNSUPPORTED, "acceleration structure larger than 4 GiB per array (more than 89 M triangles)");
     for (LeafTri &t : hs.bvh.tris) { const int32_t e = hs.shapes[t.shape].emitter; t.emitter = e >= 0 ? (uint32_t)e + 1u : 0u; }
     return KKD_OK;
 }
@@ -310,6 +312,7 @@ static int uploadHostScene(kkd_ctx *ctx, const HostScene &hs, const kkd_scene_de
     if (gpuBuild) {
         /* KKD_FLAG_GPU_BUILD: the tree is built from the vertex and index arrays that are on the device already */
         const uint32_t nTris = (uint32_t)sd->n_tris;
+        if ((uint64_t)nTris * sizeof(Node4) > kMaxAccelBytes) return fail(ctx, KKD_ERR_UNSUPPORTED, "acceleration structure larger than 4 GiB per array");
         hipError_t e = ctx->nodes.ensure((size_t)nTris * sizeof(Node4));
         if (e == hipSuccess) e = ctx->wideNodes.ensure((size_t)nTris * sizeof(WideNode));
         if (e == hipSuccess) e = ctx->tris.ensure((size_t)nTris * sizeof(LeafTri));

@@ -45,6 +45,62 @@ KKD_ENC_HD void widenNode(const Node4F &n, WideNode &out) {
     for (int k = 0; k < 4; ++k) out.child[k] = k < n.nk ? n.child[k] : 0u;
 }
 
+#ifdef KKD_NODE_FP16
+/* half <-> float for the non-negative plane coordinates of the fp16 node layout, with directed rounding (bit arithmetic, the
+ * same on host and device).  Values below the smallest normal half (2^-14) round to 0 / up to 2^-14. */
+KKD_ENC_HD float halfBitsToFloat(uint16_t h) {
+    if ((h & 0x7fffu) == 0u) return 0.f;
+    const uint32_t u = ((((uint32_t)h >> 10) & 0x1fu) - 15u + 127u) << 23 | ((uint32_t)h & 0x3ffu) << 13;
+    float f; memcpy(&f, &u, 4); return f;
+}
+KKD_ENC_HD uint16_t halfFloorBits(float x) {
+    if (!(x >= 6.103515625e-05f)) return 0;
+    if (x >= 65504.f) return 0x7bff;
+    uint32_t u; memcpy(&u, &x, 4);
+    return (uint16_t)((((u >> 23) - 127u + 15u) << 10) | ((u >> 13) & 0x3ffu));
+}
+KKD_ENC_HD uint16_t halfCeilBits(float x) {
+    if (!(x > 0.f)) return 0;
+    if (x <= 6.103515625e-05f) return 0x0400;
+    uint32_t u; memcpy(&u, &x, 4);
+    uint16_t h = halfFloorBits(x);
+    if ((u & 0x1fffu) != 0u && h < 0x7bff) ++h;
+    return h;
+}
+KKD_ENC_HD float decodePlaneH(uint16_t h, float scale, float origin) { return fmaf(halfBitsToFloat(h), scale, origin); }
+
+/* fp16 encoding of a node's child boxes: per axis origin = min over the children, scale = smallest power of two with extent <=
+ * 2047 * scale; min planes round down, max planes up, each checked through the kernel's decode. */
+KKD_ENC_HD void quantizeNode(const Node4F &n, Node4 &out) {
+    memset(&out, 0, sizeof(out));
+    const float *mins[3] = { n.minx, n.miny, n.minz }, *maxs[3] = { n.maxx, n.maxy, n.maxz };
+    uint16_t *hmins[3] = { out.hminx, out.hminy, out.hminz }, *hmaxs[3] = { out.hmaxx, out.hmaxy, out.hmaxz };
+    float origin[3]; uint8_t expo[3];
+    for (int a = 0; a < 3; ++a) {
+        float lo = INFINITY, hi = -INFINITY;
+        for (int k = 0; k < n.nk; ++k) { lo = fminf(lo, mins[a][k]); hi = fmaxf(hi, maxs[a][k]); }
+        origin[a] = lo;
+        const float extent = hi - lo;
+        int e = 0;
+        if (extent > 0.f) { frexpf(extent / 2047.0f, &e); }
+        else e = -126;
+        e = e < -126 ? -126 : (e > 127 ? 127 : e);
+        float scale = ldexpf(1.0f, e);
+        while (e < 127 && decodePlaneH(0x6bff /* 4094 */, scale, lo) < hi) { ++e; scale = ldexpf(1.0f, e); }
+        expo[a] = (uint8_t)(e + 127);
+        for (int k = 0; k < 4; ++k) {
+            if (k >= n.nk) { hmins[a][k] = 0x7bff; hmaxs[a][k] = 0; continue; }
+            uint16_t h0 = halfFloorBits((mins[a][k] - lo) / scale), h1 = halfCeilBits((maxs[a][k] - lo) / scale);
+            while (h0 > 0 && decodePlaneH(h0, scale, lo) > mins[a][k]) h0 = h0 == 0x0400 ? 0 : (uint16_t)(h0 - 1);
+            while (h1 < 0x7bff && decodePlaneH(h1, scale, lo) < maxs[a][k]) h1 = h1 == 0 ? 0x0400 : (uint16_t)(h1 + 1);
+            hmins[a][k] = h0; hmaxs[a][k] = h1;
+        }
+    }
+    out.ox = origin[0]; out.oy = origin[1]; out.oz = origin[2];
+    out.ex = expo[0]; out.ey = expo[1]; out.ez = expo[2]; out.epad = 0;
+    for (int k = 0; k < 4; ++k) out.child[k] = k < n.nk ? n.child[k] : 0u;
+}
+#else
 KKD_ENC_HD void quantizeNode(const Node4F &n, Node4 &out) {
     memset(&out, 0, sizeof(out));
     const float *mins[3] = { n.minx, n.miny, n.minz }, *maxs[3] = { n.maxx, n.maxy, n.maxz };
@@ -76,6 +132,7 @@ KKD_ENC_HD void quantizeNode(const Node4F &n, Node4 &out) {
     out.ex = expo[0]; out.ey = expo[1]; out.ez = expo[2]; out.epad = 0;
     for (int k = 0; k < 4; ++k) out.child[k] = k < n.nk ? n.child[k] : 0u;
 }
+#endif
 
 
 } /* namespace kkd */

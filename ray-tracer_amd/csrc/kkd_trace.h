@@ -180,8 +180,22 @@ struct Walk {
             if (__ballot(atNode || pend != 0u || cur != kTraversalDone) == 0ull) break;
             if (atNode) {
                 if (COUNT) ++nNodes;
-                const uint4 *n = nodes4 + (size_t)cur * 4;
+#ifndef KKD_OFS64   /* 64-bit record addresses: developer switch (round 3 measured the 32-bit form 1 % faster in the traversal stages) */
+    /* 32-bit byte offsets from a scalar base (global_load ... v_off, s[base]): one shift per record address instead of 64-bit
+     * arithmetic; x * 48 and x * 80 as shift-adds (a 32-bit multiply is quarter rate).  The upload refuses trees whose node or
+     * triangle array exceeds 4 GiB (kMaxAccelBytes: 67 M nodes, 89 M triangles). */
+    #define KKD_REC(BASE, INDEX, BYTES) reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(BASE) + (size_t)( \
+        (BYTES) == 48 ? ((((uint32_t)(INDEX) << 1) + (uint32_t)(INDEX)) << 4) : (BYTES) == 80 ? ((((uint32_t)(INDEX) << 2) + (uint32_t)(INDEX)) << 4) : ((uint32_t)(INDEX) * (uint32_t)(BYTES))))
+#else
+    #define KKD_REC(BASE, INDEX, BYTES) ((BASE) + (size_t)(INDEX) * ((BYTES) / 16))
+#endif
+#ifdef KKD_NODE_FP16
+                const uint4 *n = KKD_REC(nodes4, cur, 80);
+                const uint4 hd = n[0], ch = n[1], ha = n[2], hb = n[3], hc = n[4];
+#else
+                const uint4 *n = KKD_REC(nodes4, cur, 64);
                 const uint4 hd = n[0], ch = n[1], qa = n[2], qb = n[3];
+#endif
                 const float gx = __uint_as_float(hd.x), gy = __uint_as_float(hd.y), gz = __uint_as_float(hd.z);
                 const float sx = __uint_as_float((hd.w & 0xffu) << 23), sy = __uint_as_float(((hd.w >> 8) & 0xffu) << 23),
                             sz = __uint_as_float(((hd.w >> 16) & 0xffu) << 23);
@@ -193,6 +207,27 @@ struct Walk {
                  * instead of one on each side: tn >= 0 on this path). */
                 const float tax = sx * idx, tay = sy * idy, taz = sz * idz;
                 const float tbx = (gx - ox) * idx, tby = (gy - oy) * idy, tbz = (gz - oz) * idz;
+#ifdef KKD_NODE_FP16
+                /* ha = minx | miny, hb = minz | maxx, hc = maxy | maxz: two words of two halves per axis and side */
+                typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+                const uint32_t nxA = negx ? hb.z : ha.x, nxB = negx ? hb.w : ha.y, fxA = negx ? ha.x : hb.z, fxB = negx ? ha.y : hb.w;
+                const uint32_t nyA = negy ? hc.x : ha.z, nyB = negy ? hc.y : ha.w, fyA = negy ? ha.z : hc.x, fyB = negy ? ha.w : hc.y;
+                const uint32_t nzA = negz ? hc.z : hb.x, nzB = negz ? hc.w : hb.y, fzA = negz ? hb.x : hc.z, fzB = negz ? hb.y : hc.w;
+    #define KKD_H(W, I) ((float)__builtin_bit_cast(half2v, W)[I])
+    #define KKD_SLAB(D, NX, FX, NY, FY, NZ, FZ, I, C) { \
+                const float tnx = fmaf(KKD_H(NX, I), tax, tbx), tfx = fmaf(KKD_H(FX, I), tax, tbx); \
+                const float tny = fmaf(KKD_H(NY, I), tay, tby), tfy = fmaf(KKD_H(FY, I), tay, tby); \
+                const float tnz = fmaf(KKD_H(NZ, I), taz, tbz), tfz = fmaf(KKD_H(FZ, I), taz, tbz); \
+                const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin)); \
+                const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tmax)); \
+                D = (tn <= tf * 1.000002f && (C) != 0u) ? tn : kInf; }
+                KKD_SLAB(d0, nxA, fxA, nyA, fyA, nzA, fzA, 0, ch.x)
+                KKD_SLAB(d1, nxA, fxA, nyA, fyA, nzA, fzA, 1, ch.y)
+                KKD_SLAB(d2, nxB, fxB, nyB, fyB, nzB, fzB, 0, ch.z)
+                KKD_SLAB(d3, nxB, fxB, nyB, fyB, nzB, fzB, 1, ch.w)
+    #undef KKD_SLAB
+    #undef KKD_H
+#else
                 const uint32_t nx4 = negx ? qa.w : qa.x, fx4 = negx ? qa.x : qa.w;
                 const uint32_t ny4 = negy ? qb.x : qa.y, fy4 = negy ? qa.y : qb.x;
                 const uint32_t nz4 = negz ? qb.y : qa.z, fz4 = negz ? qa.z : qb.y;
@@ -208,6 +243,7 @@ struct Walk {
                 KKD_SLAB(d2, 2, ch.z)
                 KKD_SLAB(d3, 3, ch.w)
     #undef KKD_SLAB
+#endif
                 uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
                 if (ANY) {
                     /* occlusion does not depend on the order of the walk, and a ray that reaches its light visits every box it
@@ -246,7 +282,7 @@ struct Walk {
                 if (pend != 0u) {
                     const uint32_t slot = pend & kLeafStartMask;
                     if (COUNT) ++nTris;
-                    const float4 *tp = tris4 + 3u * slot;   /* 32-bit shift-add, not a quarter-rate 64-bit multiply */
+                    const float4 *tp = reinterpret_cast<const float4 *>(KKD_REC(reinterpret_cast<const uint4 *>(tris4), slot, 48));   /* 32-bit shift-add, not a quarter-rate 64-bit multiply */
                     const float4 a = tp[0], b = tp[1], c = tp[2];
                     float t, u, v;
                     /* of two triangles hit at the same distance the one with the lower primitive id is reported, whatever the order
@@ -268,6 +304,7 @@ struct Walk {
         }
 #undef KKD_PUSH
 #undef KKD_POP
+#undef KKD_REC
     }
 };
 

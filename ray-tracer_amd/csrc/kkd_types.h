@@ -24,6 +24,17 @@ namespace kkd {
  * The builder rounds min planes down and max planes up and verifies the float decode (same fmaf) encloses the true
  * box.  child[i]: 0 = empty slot (the root is never a child); bit31 set = leaf, bits 28..30 = triangle count - 1,
  * bits 0..27 = first LeafTri slot; otherwise index of the child node. */
+#ifdef KKD_NODE_FP16
+/* Experimental layout (round 3, -DKKD_NODE_FP16): child planes as half floats in units of the node's grid scale, 80 bytes =
+ * five 16-byte loads.  v_fma_mix_f32 reads a half operand directly, so a plane costs ONE instruction (t = h * ta + tb) instead
+ * of a byte->float conversion and an fma, and 11 bits of mantissa give tighter boxes than the 8-bit grid. */
+struct alignas(16) Node4 {
+    float ox, oy, oz;            /* grid origin = min corner of the node box                    */
+    uint8_t ex, ey, ez, epad;    /* biased exponents of the per-axis grid scale                 */
+    uint32_t child[4];
+    uint16_t hminx[4], hminy[4], hminz[4], hmaxx[4], hmaxy[4], hmaxz[4];
+};
+#else
 struct alignas(64) Node4 {
     float ox, oy, oz;            /* grid origin = min corner of the node box                    */
     uint8_t ex, ey, ez, epad;    /* biased exponents of the per-axis grid scale                 */
@@ -31,10 +42,13 @@ struct alignas(64) Node4 {
     uint8_t qminx[4], qminy[4], qminz[4], qmaxx[4];
     uint8_t qmaxy[4], qmaxz[4]; uint32_t pad[2];
 };
+#endif
 static constexpr uint32_t kLeafBit = 0x80000000u;
 static constexpr uint32_t kLeafStartMask = 0x0FFFFFFFu;
 static constexpr uint32_t kTraversalDone = 0xFFFFFFFFu;   /* never a leaf reference: LeafTri slots stay below kLeafStartMask */
 static constexpr int kMaxLeafTris = 4;
+/* the per-lane walk addresses node and triangle records by 32-bit byte offsets (kkd_trace.h) */
+static constexpr uint64_t kMaxAccelBytes = 0xFFFFFFFFull;
 
 /* The same tree with full-float child boxes, for the packet traversal of primary rays (one wave = the samples of one pixel
  * or of a few neighbouring pixels): the node is fetched ONCE per wave through the scalar cache, so its size costs no

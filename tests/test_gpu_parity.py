@@ -96,7 +96,7 @@ def test_hit_ids_sponza_class_primary_and_secondary(gpu):
         assert st.class_rays[abi.RAYS_BSDF] == len(cam) and st.nodes_visited > len(cam) and st.tris_tested > 0
         assert st.algorithmic_bytes > 48 * len(cam)
         info = ctx.accel_info()
-        assert info["node_bytes"] == 64 and info["tri_bytes"] == 48 and info["n_leaf_tris"] == sc._nt
+        assert info["node_bytes"] in (64, 80) and info["tri_bytes"] == 48 and info["n_leaf_tris"] == sc._nt
 
 
 def test_hit_ids_watertight_mode(gpu):
