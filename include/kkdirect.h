@@ -333,12 +333,14 @@ int kkd_trace(kkd_ctx *ctx, const float *rays, uint64_t n, int any_hit, kkd_hit 
  * the measurement protocol of src/utils/kdbench.cpp:210-242 times them. */
 int kkd_trace_device(kkd_ctx *ctx, const void *dev_rays, uint64_t n, int any_hit, void *dev_out, kkd_stats *stats);
 
-/* kkd_trace_device for callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc.  No counterpart in the reference (its CPU path has no device memory to allocate).
- * Same queries, same results and statistics as kkd_trace_device, but the call makes no hipMalloc / hipFree / event or
- * stream creation and no host allocation: the sharded ray counters of the launch, which kkd_trace_device keeps in a buffer
- * of the context, live in a file-scope device array of the library (128 KiB on every GPU the library runs on, held until
- * the process ends; looked up once per device by kkd_create).  dev_rays / dev_out are caller-owned device memory as for
+/* kkd_trace_device for callers that cannot allocate device memory: tight serving loops, harnesses that forbid hipMalloc,
+ * code that must not disturb an allocator while other work is being captured or replayed.  No counterpart in the reference
+ * (its CPU path has no device memory to allocate).  Same queries, same results and statistics as kkd_trace_device; on the
+ * success path the call makes no hipMalloc / hipFree / event or stream creation and no host allocation (an error builds its
+ * message in a std::string): the sharded ray counters of the launch, which kkd_trace_device keeps in a buffer of the context,
+ * live in a file-scope device array of the library (128 KiB on every GPU the library runs on, held until the process ends;
+ * looked up once per device by kkd_create).  The call is NOT itself capturable into a HIP graph: it runs on the context's
+ * private stream, records timing events, copies the counters back and synchronises before it returns.  dev_rays / dev_out are caller-owned device memory as for
  * kkd_trace_device.  At most KKD_NOALLOC_MAX_RAYS rays per call (one launch), more is refused with KKD_ERR_UNSUPPORTED.
  * All calls on one GPU share that GPU's array: it is cleared at the start of every call, and calls that overlap on one GPU
  * (two contexts, two threads) race on the counters -- their hits stay correct, their statistics do not. */
@@ -523,7 +525,7 @@ int kkd_set_progress_callback(kkd_ctx *ctx, kkd_progress_fn fn, void *user);
  * render thread with the work items whose results the copy holds.  The buffer is valid during the call only; develop it
  * with kkd_develop or write it with the kkd_write_* functions.  A request that arrives after the last batch was queued is
  * dropped: the finished film follows anyway.  Costs one drain of the pipeline and one copy per request.  fn == NULL removes
- * the callback.  Single context only: kkd_multi_* deliver the merged film at the end of the render. */
+ * the callback.  (kkd_multi_set_flush_callback / kkd_multi_request_flush do the same for a multi-device job.) */
 typedef void (*kkd_flush_fn)(void *user, const float *film, uint32_t width, uint32_t height, uint64_t samples_done, uint64_t samples_total);
 int kkd_set_flush_callback(kkd_ctx *ctx, kkd_flush_fn fn, void *user);
 void kkd_request_flush(kkd_ctx *ctx);
@@ -579,6 +581,20 @@ int kkd_multi_set_progress_callback(kkd_multi *m, kkd_progress_fn fn, void *user
 /* how the last render merged its films: "single", "tile-gather", "rccl-reduce" or "copy-add" (measurement / tests; the
  * reference logs its scheduler set-up the same way, src/librender/integrator.cpp:102-109) */
 const char *kkd_multi_merge_path(kkd_multi *m);
+/* what kkd_multi_create found on this machine, as text: the device list, for every (root, device) pair whether
+ * hipDeviceCanAccessPeer allows direct copies in either direction and whether enabling them succeeded, and (sample-split
+ * mode) which librccl was loaded and its version -- so that a failing first run on real devices names its cause.  Also
+ * printed to stderr by kkd_multi_create when $KKD_MULTI_VERBOSE is set.  The reference logs its worker set-up likewise
+ * (src/mitsuba/mitsuba.cpp:260-309). */
+const char *kkd_multi_diagnostics(kkd_multi *m);
+/* kkd_set_flush_callback / kkd_request_flush for the whole job (`mitsuba -r <seconds>`, src/mitsuba/mitsuba.cpp:105-125 ->
+ * RenderQueue::flush, src/librender/renderqueue.cpp:73-78): every device answers the request between two of its batches (or
+ * with its finished film, if its share is done) with a copy of ITS film; the films of a tile-sharded or sample-split job add
+ * up to the job's film, so the device that completes the round calls fn, on its render thread, with the sum (host memory,
+ * valid during the call) and the work items it holds.  A request that arrives while a round is being collected is answered
+ * with the finished films at the end of the render.  fn == NULL removes the callback. */
+int kkd_multi_set_flush_callback(kkd_multi *m, kkd_flush_fn fn, void *user);
+void kkd_multi_request_flush(kkd_multi *m);
 uint32_t kkd_multi_device_count(kkd_multi *m);   /* contexts behind the handle (src/librender/integrator.cpp:102: getCoreCount) */
 const char *kkd_multi_last_error(kkd_multi *m);  /* as kkd_last_error (src/librender/renderjob.cpp:111-115) */
 /* releases every context (the reference tears its workers down in Scheduler::staticShutdown, src/mitsuba/mitsuba.cpp:436) */

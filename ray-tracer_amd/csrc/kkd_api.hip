@@ -593,52 +593,67 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
      * ray, ~0.4 ms with the device nearly idle, so fewer, larger batches are faster: C4 2720 / 2796 / 2841 / 2885 / 2898 / 2903
      * Msamples/s at 8 / 16 / 32 / 64 / 128 / 256 M samples per batch (C2: 3184 / 3227 / 3237 / 3260 / 3284 / 3297) */
     const uint64_t perSample = std::max<uint64_t>(1, std::max(pathMode ? 1u : rp->bsdf_samples, pathMode ? 1u : rp->light_samples));
-    uint64_t batch = ctx->cfg.max_samples_in_flight ? ctx->cfg.max_samples_in_flight : std::max<uint64_t>(1ull << 20, (1ull << 26) / perSample);
-    batch = std::max<uint64_t>(256, (batch + 255) / 256 * 256);
-    batch = std::min<uint64_t>(batch, 1ull << 28);
-    batch = std::min<uint64_t>(batch, std::max<uint64_t>(256, (total + 255) / 256 * 256));
     static const int envLanesDefault = [] { const char *e = getenv("KKD_STREAMS"); return envInt(e, 2, 1, kMaxLanes); }();
-    const int envLanes = (ctx->cfg.flags & KKD_FLAG_ONE_LANE) ? 1 : envLanesDefault;
-    if (!ctx->cfg.max_samples_in_flight && envLanes >= 2 && total >= (1ull << 21)) {
-        /* library default: an even number of equal batches, so both batch lanes (below) work to the end */
-        uint64_t nb = (total + batch - 1) / batch;
-        nb = std::max<uint64_t>(2, nb + (nb & 1));
-        batch = ((total + nb - 1) / nb + 255) / 256 * 256;
-    }
     const uint32_t nB = pathMode ? 1u : rp->bsdf_samples, nL = pathMode ? 1u : rp->light_samples;   /* path.cpp: one of each per vertex */
-    const size_t S = (size_t)batch;
-
-    const uint64_t nBatches = (total + batch - 1) / batch;
-    /* Batch lanes: consecutive batches alternate between two streams with their own wavefront buffers, so the
-     * issue-bound kernels of one batch (sample generation, shading, splat) fill the issue slots the latency-bound
-     * traversal kernels of the other leave idle.  Batches only meet in the film and the counters (atomic adds).
-     * $KKD_STREAMS=1 switches back to one lane. */
-    const int nLanes = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min(envLanes, kMaxLanes), nBatches));
-    hipError_t e = hipSuccess;
-    for (int l = 1; l < nLanes && e == hipSuccess; ++l)
-        if (!ctx->laneStreams[l - 1]) e = hipStreamCreateWithFlags(&ctx->laneStreams[l - 1], hipStreamNonBlocking);
-    if (e != hipSuccess) return fail(ctx, KKD_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
-    auto need = [&](DevBuf &b, size_t bytes) { if (e == hipSuccess) e = b.ensure(bytes); };
-    auto needL = [&](DevBuf &b, size_t bytes) { if (e == hipSuccess) e = b.ensure(((bytes + 255) / 256 * 256) * nLanes); };   /* one copy per lane */
-    auto laneP = [&](DevBuf &b, size_t bytes, int lane) { return (char *)b.p + ((bytes + 255) / 256 * 256) * lane; };
-    needL(ctx->hits, S * sizeof(DHit)); needL(ctx->accum, S * 16); needL(ctx->refN, S * 16);
-    needL(ctx->bsdfRays, S * nB * sizeof(DRay)); needL(ctx->bsdfHits, S * nB * sizeof(DHit)); needL(ctx->brec0, S * nB * 16);
-    /* continuation buffer of the two-launch traversal: a quarter of the largest ray launch may be parked */
     /* $KKD_ITER_CAP_CLOSEST / _ANY pin the budgets (0 = one launch, no rounds); else they adapt, see below */
     static const int envCapClosest = [] { const char *e = getenv("KKD_ITER_CAP_CLOSEST"); return envInt(e, -1, 0, 4096); }();
     static const int envCapAny = [] { const char *e = getenv("KKD_ITER_CAP_ANY"); return envInt(e, -1, 0, 4096); }();
     const int capClosest = envCapClosest >= 0 ? envCapClosest : ctx->capClosest, capAny = envCapAny >= 0 ? envCapAny : ctx->capAny;
-    const uint64_t contCap = std::min<uint64_t>(((uint64_t)S * std::max(nB, nL) / 2 / kContShards + 128) * kContShards, 0x7fffffffull);   /* two halves of n/4 records */
-    needL(ctx->contRecs, contCap * sizeof(ContRec)); needL(ctx->contStacks, contCap * 16 * sizeof(uint32_t)); needL(ctx->contCount, 4 * kContShards * 32 * sizeof(uint32_t));   /* closest: 2 ping-pong counter arrays, any: 2 */
-    needL(ctx->shadowRays, S * nL * sizeof(DRay)); needL(ctx->occluded, S * nL * 4); needL(ctx->lrec, S * nL * 16);
-    need(ctx->counters, kCounterShards * sizeof(DeviceCounters));
-    if (pathMode) {   /* slot counters and the second set of path arrays (compaction ping-pong) */
-        needL(ctx->pathAlive, (kAliveShards + 1) * sizeof(uint32_t));
-        needL(ctx->pBsdfRays, S * sizeof(DRay)); needL(ctx->pBrec, S * 16); needL(ctx->pRefN, S * 16);
-        needL(ctx->pShadowRays, S * sizeof(DRay)); needL(ctx->pLrec, S * 16); needL(ctx->pSampleIdx, 2 * S * sizeof(uint32_t));
+    /* Batch lanes: consecutive batches alternate between two streams with their own wavefront buffers, so the
+     * issue-bound kernels of one batch (sample generation, shading, splat) fill the issue slots the latency-bound
+     * traversal kernels of the other leave idle.  Batches only meet in the film and the counters (atomic adds).
+     * $KKD_STREAMS=1 switches back to one lane. */
+    int envLanes = (ctx->cfg.flags & KKD_FLAG_ONE_LANE) ? 1 : envLanesDefault;
+    uint64_t batchCap = ctx->cfg.max_samples_in_flight ? ctx->cfg.max_samples_in_flight : std::max<uint64_t>(1ull << 20, (1ull << 26) / perSample);
+    uint64_t batch = 0, nBatches = 0, contCap = 0; size_t S = 0; int nLanes = 1;
+    hipError_t e = hipSuccess;
+    auto laneP = [&](DevBuf &b, size_t bytes, int lane) { return (char *)b.p + ((bytes + 255) / 256 * 256) * lane; };
+    /* The wavefront buffers are sized by the batch (~0.2 KB per camera sample and lane: 28 GB for two lanes of 64 M samples).
+     * On a device that cannot give that much -- a smaller part, or one shared with other contexts or another tenant -- the
+     * batch is halved down to 1 M samples, then the second lane is dropped, before the render gives up with KKD_ERR_NOMEM. */
+    for (int attempt = 0;; ++attempt) {
+        batch = std::max<uint64_t>(256, (batchCap + 255) / 256 * 256);
+        batch = std::min<uint64_t>(batch, 1ull << 28);
+        batch = std::min<uint64_t>(batch, std::max<uint64_t>(256, (total + 255) / 256 * 256));
+        if ((!ctx->cfg.max_samples_in_flight || attempt > 0) && envLanes >= 2 && total >= (1ull << 21)) {
+            /* library default: an even number of equal batches, so both batch lanes work to the end */
+            uint64_t nb = (total + batch - 1) / batch;
+            nb = std::max<uint64_t>(2, nb + (nb & 1));
+            batch = ((total + nb - 1) / nb + 255) / 256 * 256;
+        }
+        S = (size_t)batch;
+        nBatches = (total + batch - 1) / batch;
+        nLanes = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min(envLanes, kMaxLanes), nBatches));
+        e = hipSuccess;
+        for (int l = 1; l < nLanes && e == hipSuccess; ++l)
+            if (!ctx->laneStreams[l - 1]) e = hipStreamCreateWithFlags(&ctx->laneStreams[l - 1], hipStreamNonBlocking);
+        if (e != hipSuccess) return fail(ctx, KKD_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+        auto need = [&](DevBuf &b, size_t bytes) { if (e == hipSuccess) e = b.ensure(bytes); };
+        auto needL = [&](DevBuf &b, size_t bytes) { if (e == hipSuccess) e = b.ensure(((bytes + 255) / 256 * 256) * nLanes); };   /* one copy per lane */
+        needL(ctx->hits, S * sizeof(DHit)); needL(ctx->accum, S * 16); needL(ctx->refN, S * 16);
+        needL(ctx->bsdfRays, S * nB * sizeof(DRay)); needL(ctx->bsdfHits, S * nB * sizeof(DHit)); needL(ctx->brec0, S * nB * 16);
+        /* continuation buffer of the two-launch traversal: half of the largest ray launch may be parked */
+        contCap = std::min<uint64_t>(((uint64_t)S * std::max(nB, nL) / 2 / kContShards + 128) * kContShards, 0x7fffffffull);
+        needL(ctx->contRecs, contCap * sizeof(ContRec)); needL(ctx->contStacks, contCap * 16 * sizeof(uint32_t)); needL(ctx->contCount, 4 * kContShards * 32 * sizeof(uint32_t));   /* closest: 2 ping-pong counter arrays, any: 2 */
+        needL(ctx->shadowRays, S * nL * sizeof(DRay)); needL(ctx->occluded, S * nL * 4); needL(ctx->lrec, S * nL * 16);
+        need(ctx->counters, kCounterShards * sizeof(DeviceCounters));
+        if (pathMode) {   /* slot counters and the second set of path arrays (compaction ping-pong) */
+            needL(ctx->pathAlive, (kAliveShards + 1) * sizeof(uint32_t));
+            needL(ctx->pBsdfRays, S * sizeof(DRay)); needL(ctx->pBrec, S * 16); needL(ctx->pRefN, S * 16);
+            needL(ctx->pShadowRays, S * sizeof(DRay)); needL(ctx->pLrec, S * 16); needL(ctx->pSampleIdx, 2 * S * sizeof(uint32_t));
+        }
+        if (!devFilm) need(ctx->film, (size_t)W * H * 5 * sizeof(float));
+        if (e == hipSuccess) break;
+        if (e != hipErrorOutOfMemory) return fail(ctx, KKD_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+        (void)hipGetLastError();
+        /* give back what this attempt took (DevBuf::ensure frees before it grows, so the buffers that failed hold nothing) */
+        DevBuf *work[] = { &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->contRecs, &ctx->contStacks, &ctx->contCount,
+                           &ctx->shadowRays, &ctx->occluded, &ctx->lrec, &ctx->pathAlive, &ctx->pBsdfRays, &ctx->pBrec, &ctx->pRefN, &ctx->pShadowRays, &ctx->pLrec, &ctx->pSampleIdx };
+        for (DevBuf *b : work) b->release();
+        if (batch > (1ull << 20)) batchCap = std::max<uint64_t>(1ull << 20, batch / 2);
+        else if (envLanes > 1) envLanes = 1;
+        else return fail(ctx, KKD_ERR_NOMEM, "hipMalloc: out of memory for the wavefront buffers of 1 M samples in flight");
     }
-    if (!devFilm) need(ctx->film, (size_t)W * H * 5 * sizeof(float));
-    if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? KKD_ERR_NOMEM : KKD_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
     float *film = devFilm ? devFilm : (float *)ctx->film.p;
 
     TraceContinuation contL[kMaxLanes]; WaveBuffers wbL[kMaxLanes];
@@ -930,12 +945,14 @@ struct Rccl {
     int (*GroupEnd)() = nullptr;
     int (*Reduce)(const void *, void *, size_t, int /*ncclDataType_t*/, int /*ncclRedOp_t*/, int, Comm, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
-    void *lib = nullptr;
+    int (*GetVersion)(int *) = nullptr;
+    void *lib = nullptr; std::string loadedFrom;
     static constexpr int kFloat = 7 /* ncclFloat32 */, kSum = 0 /* ncclSum */;
     bool load() {
         if (lib) return true;
-        for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) { lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+        for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) { lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (lib) { loadedFrom = name; break; } }
         if (!lib) return false;
+        GetVersion = (decltype(GetVersion))dlsym(lib, "ncclGetVersion");
         CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll"); CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
         GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart"); GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
         Reduce = (decltype(Reduce))dlsym(lib, "ncclReduce"); GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
@@ -956,6 +973,40 @@ struct kkd_multi {
     DevBuf rootFilm;                     /* root film of kkd_multi_render (host output) */
     Rccl rccl; std::vector<Rccl::Comm> comms; bool distinct = false;
     std::string mergePath;               /* "single", "tile-gather", "rccl-reduce", "copy-add" (what the last render used) */
+    std::string diagnostics;             /* what kkd_multi_create found: peer access per device pair, librccl (kkd_multi_diagnostics) */
+    /* Film::develop during a render (kkd_multi_request_flush): every rank hands a copy of ITS film to onRankFlush (between two
+     * of its batches, or when its share is done); the films of a tile-sharded or sample-split job add up to the job's film,
+     * so the rank that completes a round calls the user's function with the sum */
+    kkd_flush_fn flushFn = nullptr; void *flushUser = nullptr;
+    struct RankFlush { kkd_multi *m; uint32_t rank; };
+    std::vector<RankFlush> rankFlush;
+    std::mutex flushMutex;
+    std::atomic<uint32_t> flushWanted{0};    /* rounds requested so far */
+    uint32_t flushRound = 0;                 /* round being collected (0 = none) */
+    std::vector<uint32_t> flushGiven;        /* per rank: the last round it contributed to */
+    std::vector<float> flushSum; uint32_t flushArrived = 0; uint64_t flushDone = 0, flushTotal = 0;
+    bool rendering = false;
+    static void onRankFlush(void *user, const float *film, uint32_t w, uint32_t h, uint64_t done, uint64_t total) {
+        RankFlush *rf = (RankFlush *)user; rf->m->contributeFlush(rf->rank, film, w, h, done, total);
+    }
+    void contributeFlush(uint32_t rank, const float *film, uint32_t w, uint32_t h, uint64_t done, uint64_t total) {
+        std::lock_guard<std::mutex> lock(flushMutex);
+        const uint32_t wanted = flushWanted.load();
+        if (flushRound == 0) {                 /* first film of a new round */
+            if (flushGiven[rank] >= wanted) return;
+            flushRound = wanted; flushArrived = 0; flushDone = flushTotal = 0;
+            flushSum.assign((size_t)w * h * 5, 0.f);
+        }
+        if (flushGiven[rank] >= flushRound) return;      /* this rank is already in */
+        flushGiven[rank] = flushRound;
+        const size_t n = (size_t)w * h * 5;
+        for (size_t i = 0; i < n; ++i) flushSum[i] += film[i];
+        flushDone += done; flushTotal += total;
+        if (++flushArrived == (uint32_t)ctx.size()) {
+            if (flushFn) flushFn(flushUser, flushSum.data(), w, h, flushDone, flushTotal);
+            flushRound = 0;
+        }
+    }
     /* progress of the whole job: the per-device reports are summed under a mutex and passed on */
     kkd_progress_fn progressFn = nullptr; void *progressUser = nullptr;
     struct RankProgress { kkd_multi *m; uint32_t rank; };
@@ -990,14 +1041,35 @@ kkd_multi *kkd_multi_create(const kkd_multi_config *cfg) {
     m->packed.resize(n); m->staging.resize(n); m->rankTiles.resize(n);
     m->distinct = true;
     for (size_t a = 0; a < n; ++a) for (size_t b = a + 1; b < n; ++b) if (m->ctx[a]->device == m->ctx[b]->device) m->distinct = false;
+    /* What the first run on real devices needs to name the cause of a failure: peer access per pair and the RCCL library, kept
+     * as text (kkd_multi_diagnostics) and printed to stderr when $KKD_MULTI_VERBOSE is set. */
+    std::string &dg = m->diagnostics;
+    dg = "devices:";
+    for (size_t r = 0; r < n; ++r) dg += " " + std::to_string(m->ctx[r]->device);
+    dg += m->distinct ? " (distinct)" : " (a device is listed more than once: films are merged by copies on it, RCCL is not used)";
     if (m->distinct && n > 1) {           /* direct xGMI copies between the root and every other device, where the platform allows them */
         for (size_t r = 1; r < n; ++r) {
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, m->ctx[0]->device, m->ctx[r]->device) == hipSuccess && can) { hipSetDevice(m->ctx[0]->device); (void)hipDeviceEnablePeerAccess(m->ctx[r]->device, 0); }
-            if (hipDeviceCanAccessPeer(&can, m->ctx[r]->device, m->ctx[0]->device) == hipSuccess && can) { hipSetDevice(m->ctx[r]->device); (void)hipDeviceEnablePeerAccess(m->ctx[0]->device, 0); }
+            const int a = m->ctx[0]->device, b = m->ctx[r]->device;
+            int canAB = 0, canBA = 0;
+            const hipError_t qa = hipDeviceCanAccessPeer(&canAB, a, b), qb = hipDeviceCanAccessPeer(&canBA, b, a);
+            hipError_t ea = hipErrorUnknown, eb = hipErrorUnknown;
+            if (qa == hipSuccess && canAB) { hipSetDevice(a); ea = hipDeviceEnablePeerAccess(b, 0); }
+            if (qb == hipSuccess && canBA) { hipSetDevice(b); eb = hipDeviceEnablePeerAccess(a, 0); }
+            auto enabled = [](hipError_t e) { return e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled; };
+            dg += "; peer " + std::to_string(a) + "->" + std::to_string(b) + ": " + (qa != hipSuccess ? std::string("query failed: ") + hipGetErrorString(qa) : !canAB ? std::string("no") : enabled(ea) ? std::string("enabled") : std::string("enable failed: ") + hipGetErrorString(ea));
+            dg += ", " + std::to_string(b) + "->" + std::to_string(a) + ": " + (qb != hipSuccess ? std::string("query failed: ") + hipGetErrorString(qb) : !canBA ? std::string("no") : enabled(eb) ? std::string("enabled") : std::string("enable failed: ") + hipGetErrorString(eb));
         }
         (void)hipGetLastError();          /* "already enabled" is not an error */
     }
+    if (m->split == KKD_SPLIT_SAMPLE) {
+        if (m->rccl.load()) {
+            int v = 0;
+            dg += "; librccl: " + m->rccl.loadedFrom;
+            if (m->rccl.GetVersion && m->rccl.GetVersion(&v) == 0) dg += " version " + std::to_string(v);
+        } else dg += std::string("; librccl: not loaded (") + (dlerror() ? "dlopen failed" : "symbols missing") + "): films are merged by copy + add";
+    }
+    m->flushGiven.assign(n, 0u);
+    if (getenv("KKD_MULTI_VERBOSE")) fprintf(stderr, "kkd_multi_create: %s\n", dg.c_str());
     return m;
 }
 
@@ -1036,6 +1108,26 @@ const char *kkd_multi_last_error(kkd_multi *m) { return m ? m->err.c_str() : g_g
 void kkd_multi_request_cancel(kkd_multi *m) { if (m) for (kkd_ctx *x : m->ctx) kkd_request_cancel(x); }
 uint32_t kkd_multi_device_count(kkd_multi *m) { return m ? (uint32_t)m->ctx.size() : 0u; }
 const char *kkd_multi_merge_path(kkd_multi *m) { return m ? m->mergePath.c_str() : ""; }
+const char *kkd_multi_diagnostics(kkd_multi *m) { return m ? m->diagnostics.c_str() : ""; }
+
+int kkd_multi_set_flush_callback(kkd_multi *m, kkd_flush_fn fn, void *user) {
+    if (!m) return KKD_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(m->flushMutex);
+    m->flushFn = fn; m->flushUser = user;
+    const size_t n = m->ctx.size();
+    m->rankFlush.resize(n);
+    for (size_t r = 0; r < n; ++r) {
+        m->rankFlush[r] = { m, (uint32_t)r };
+        kkd_set_flush_callback(m->ctx[r], fn ? &kkd_multi::onRankFlush : nullptr, &m->rankFlush[r]);
+    }
+    return KKD_OK;
+}
+
+void kkd_multi_request_flush(kkd_multi *m) {
+    if (!m || !m->flushFn) return;
+    m->flushWanted.fetch_add(1);
+    for (kkd_ctx *x : m->ctx) kkd_request_flush(x);
+}
 
 int kkd_multi_scene_upload(kkd_multi *m, const kkd_scene_desc *sd) {
     if (!m) return KKD_ERR_INVALID;
@@ -1082,6 +1174,19 @@ static int multiRender(kkd_multi *m, const kkd_render_params *rp, float *rootDev
     auto worker = [&](uint32_t r) {
         kkd_ctx *x = m->ctx[r];
         rcs[r] = renderImpl(x, &prm[r], r == 0 ? rootDevFilm : nullptr, &st[r]);      /* ranks > 0 render into their own film buffer */
+        if (rcs[r] == KKD_OK && m->flushFn && m->flushGiven[r] < m->flushWanted.load()) {
+            /* a flush was requested that this rank did not get to answer between two batches (its share was done, or the
+             * request came after its last batch was queued): its finished film completes the round */
+            const size_t bytes = filmFloats * sizeof(float);
+            hipSetDevice(x->device);
+            if (x->flushHostBytes < bytes) {
+                if (x->flushHost) { hipHostFree(x->flushHost); x->flushHost = nullptr; x->flushHostBytes = 0; }
+                if (hipHostMalloc((void **)&x->flushHost, bytes, hipHostMallocDefault) == hipSuccess) x->flushHostBytes = bytes;
+            }
+            const float *src = r == 0 ? rootDevFilm : (const float *)x->film.p;
+            if (x->flushHostBytes >= bytes && hipMemcpy(x->flushHost, src, bytes, hipMemcpyDeviceToHost) == hipSuccess)
+                m->contributeFlush(r, x->flushHost, (uint32_t)W, (uint32_t)H, st[r].samples, st[r].samples);
+        }
         if (rcs[r] != KKD_OK || r == 0 || !gather) return;
         /* tile mode: pack this rank's tiles (with borders) and send them to the root device in one copy */
         /* the rank's tile count is a function of the grid alone (nTilesOf, filled in with the staging buffers below): never
@@ -1112,6 +1217,10 @@ static int multiRender(kkd_multi *m, const kkd_render_params *rp, float *rootDev
             if (e == hipSuccess && !list.empty()) e = hipMemcpy(m->rankTiles[r].p, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
             if (e != hipSuccess) return mfail(m, e == hipErrorOutOfMemory ? KKD_ERR_NOMEM : KKD_ERR_DEVICE, std::string("tile gather buffers: ") + hipGetErrorString(e));
         }
+    }
+    {   /* flush rounds do not outlive a render */
+        std::lock_guard<std::mutex> lock(m->flushMutex);
+        m->flushWanted.store(0); m->flushRound = 0; m->flushGiven.assign(n, 0u);
     }
     if (m->progressFn) {   /* every rank's total is known only once it reports: start from "nothing done of nothing" */
         std::lock_guard<std::mutex> lock(m->progressMutex);

@@ -222,9 +222,26 @@ class MultiContext:
         self._progress = abi.PROGRESS_FN(lambda user, done, total: fn(done, total)) if fn else abi.PROGRESS_FN()
         self._check(self.lib.kkd_multi_set_progress_callback(self.h, self._progress, None))
 
+    def set_flush_callback(self, fn):
+        """fn(film[H, W, 5] copy, work_items_done, work_items_total) answers request_flush(): the job's film so far, summed over
+        the devices (kkd_multi_set_flush_callback); None removes it."""
+        def thunk(user, film, w, h, done, total):
+            fn(np.ctypeslib.as_array(film, shape=(h, w, 5)).copy(), done, total)
+        self._flush = abi.FLUSH_FN(thunk) if fn else abi.FLUSH_FN()
+        self._check(self.lib.kkd_multi_set_flush_callback(self.h, self._flush, None))
+
+    def request_flush(self):
+        """asynchronous, thread-safe, allowed inside the progress callback (kkd_multi_request_flush)"""
+        self.lib.kkd_multi_request_flush(self.h)
+
     @property
     def merge_path(self):
         return self.lib.kkd_multi_merge_path(self.h).decode()
+
+    @property
+    def diagnostics(self):
+        """what kkd_multi_create found: peer access per device pair, librccl and its version (kkd_multi_diagnostics)"""
+        return self.lib.kkd_multi_diagnostics(self.h).decode()
 
     def render(self, spp, bsdf_samples=1, light_samples=1, hide_emitters=False, block_size=0, tile_index=0, tile_count=1,
                sample_first=0, integrator=abi.INTEGRATOR_KK, strict_normals=False, max_depth=-1, rr_depth=5,

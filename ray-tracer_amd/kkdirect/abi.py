@@ -161,6 +161,9 @@ ENTRY_POINTS = {
     "kkd_multi_request_cancel": (None, [C.c_void_p]),
     "kkd_multi_set_progress_callback": (C.c_int, [C.c_void_p, PROGRESS_FN, C.c_void_p]),
     "kkd_multi_merge_path": (C.c_char_p, [C.c_void_p]),
+    "kkd_multi_diagnostics": (C.c_char_p, [C.c_void_p]),
+    "kkd_multi_set_flush_callback": (C.c_int, [C.c_void_p, FLUSH_FN, C.c_void_p]),
+    "kkd_multi_request_flush": (None, [C.c_void_p]),
     "kkd_multi_device_count": (u32, [C.c_void_p]),
     "kkd_multi_last_error": (C.c_char_p, [C.c_void_p]),
     "kkd_multi_destroy": (None, [C.c_void_p]),

@@ -128,11 +128,21 @@ def test_full_size_c3_many_lights(gpu, record_property):
     _crop_parity(gpu, sc1, (832, 476, 256, 128), 16, 5e-4)
 
 
+_C4 = {}
+
+
+def _c4_scene():
+    """C4 / C5 share one scene: generated once per session (10.7 M triangles take a while in numpy)"""
+    if "sc" not in _C4:
+        _C4["sc"] = scenes.scanned_mesh(3840, 2160)
+    return _C4["sc"]
+
+
 def test_full_size_c4_scanned_mesh(gpu, record_property):
     """C4 at its full size: 10.7 M triangles (roughconductor GGX mesh, dielectric objects, ground) under a 4096x2048 HDR
     environment map with the two-level sampling table, 3840x2160; the frame properties at a reduced spp (the full 512 spp
     frame is what bench.py times)."""
-    sc = scenes.scanned_mesh(3840, 2160)
+    sc = _c4_scene()
     assert sc._nt > 10_000_000
     o = kkoracle.Oracle(sc)
     report = []
@@ -146,3 +156,37 @@ def test_full_size_c4_scanned_mesh(gpu, record_property):
         info = ctx.accel_info()
         assert info["n_leaf_tris"] == sc._nt
         _frame_properties(ctx, 3840, 2160, 32, tiles=(8,))
+
+
+def test_c5_partitioning_at_4096_spp(gpu, record_property):
+    """C5 = the C4 scene at 4096 spp, tile-sharded vs sample-split (BASELINE.json configs[4]).  The test box has one GPU, so
+    device 0 is listed EIGHT times: eight contexts with their own streams, scene copies and films render their shares side by
+    side, and the merge code of both modes (tile gather with borders, film add; the reference's counterpart is
+    BlockedRenderProcess::processResult -> Film::put, librender/renderproc.cpp:142-149, over the work units of
+    librender/imageproc.cpp:28-78) runs for real, at the config's own sample count on a crop window of the 4K film.  What
+    this cannot show is the peer copy between distinct devices and RCCL with more than one rank: the scaling curve on
+    hardware stays the driver's to measure."""
+    sc = _c4_scene()
+    s = sc.sensor
+    crop = (1792, 1016, 256, 128)
+    s.crop_offset_x, s.crop_offset_y, s.crop_width, s.crop_height = crop
+    spp, n = 4096, crop[2] * crop[3] * 4096
+    try:
+        with gpu.Context(device=0, seed=9).upload(sc) as ctx:
+            full, st = ctx.render(spp)
+        assert st.samples == n and np.isfinite(full).all() and full.min() >= 0
+        films = {}
+        for split in ("tile", "sample"):
+            with gpu.MultiContext([0] * 8, split=split, seed=9).upload(sc) as m:
+                films[split], sm = m.render(spp)
+                assert m.merge_path == ("tile-gather" if split == "tile" else "copy-add"), m.merge_path
+                assert "listed more than once" in m.diagnostics, m.diagnostics
+                record_property("diagnostics_" + split, m.diagnostics)
+            assert sm.samples == n and sm.class_rays[abi.RAYS_PRIMARY] == n
+            assert sm.class_rays[abi.RAYS_BSDF] == st.class_rays[abi.RAYS_BSDF] and sm.class_rays[abi.RAYS_SHADOW] == st.class_rays[abi.RAYS_SHADOW]
+            # same samples, other order of the float additions into a pixel (4096 samples x 25 pixels of footprint each)
+            np.testing.assert_allclose(films[split], full, rtol=2e-4, atol=2e-3)
+        np.testing.assert_allclose(films["tile"], films["sample"], rtol=2e-4, atol=2e-3)
+        assert abs(full[4:-4, 4:-4, 4].mean() - spp) < 0.01 * spp
+    finally:
+        s.crop_offset_x, s.crop_offset_y, s.crop_width, s.crop_height = 0, 0, s.film_width, s.film_height

@@ -89,3 +89,51 @@ def test_samplers_share_one_point_set_across_ranks(gpu, split, sampler):
     with gpu.MultiContext([0, 0], split=split, seed=6).upload(sc) as m:
         film, _ = m.render(16, sampler=sampler)
     np.testing.assert_allclose(film, full, rtol=1e-4, atol=1e-5)
+
+
+def test_more_ranks_than_tiles_after_a_normal_render(gpu):
+    """a rank that gets no tile in THIS render must not pack the tiles an earlier render on the same handle left in its list
+    (round-2 review: multiRender took the count from the context's stale list)"""
+    sc = scenes.cornell_box(100, 70)
+    with gpu.Context(device=0, seed=8).upload(sc) as ctx:
+        full, st = ctx.render(8)
+    with gpu.MultiContext([0, 0, 0], split="tile", seed=8).upload(sc) as m:
+        a, _ = m.render(8)                               # 4 x 3 tiles of 32: every rank has four
+        np.testing.assert_allclose(a, full, rtol=1e-4, atol=1e-5)
+        b, sb = m.render(8, block_size=128)              # ONE tile: ranks 1 and 2 have none
+        assert sb.samples == st.samples
+        np.testing.assert_allclose(b, full, rtol=1e-4, atol=1e-5)
+        c, _ = m.render(8, block_size=64)                # 2 x 2 tiles: rank 0 two, ranks 1 and 2 one each
+        np.testing.assert_allclose(c, full, rtol=1e-4, atol=1e-5)
+        d, _ = m.render(8)
+        np.testing.assert_allclose(d, full, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("split", ["tile", "sample"])
+def test_flush_through_the_multi_handle(gpu, split):
+    """`mitsuba -r`: kkd_multi_request_flush during a render hands out the sum of the devices' films so far (mitsuba.cpp:105-125
+    -> RenderQueue::flush); a request made before any batch has finished is answered, one made when all are queued is answered
+    with the finished films"""
+    sc = scenes.cornell_box(128, 128)
+    flushed, seen = [], []
+    with gpu.MultiContext([0, 0], split=split, seed=5, max_samples_in_flight=1 << 14).upload(sc) as m:
+        m.set_flush_callback(lambda film, done, total: flushed.append((film, done, total)))
+
+        def progress(done, total):
+            seen.append((done, total))
+            if len(seen) in (2, 9):
+                m.request_flush()
+        m.set_progress_callback(progress)
+        final, st = m.render(32)
+    assert len(seen) > 9 and flushed, (len(seen), len(flushed))
+    for film, done, total in flushed:
+        assert film.shape == final.shape and np.isfinite(film).all() and film.min() >= 0
+        assert 0 < done <= total
+        # a partial film holds a subset of the final film's samples: nowhere more (the additions differ in order only)
+        assert (film <= final * (1 + 1e-4) + 1e-4).all()
+        assert film[..., 4].sum() <= final[..., 4].sum() * (1 + 1e-5)
+    first = flushed[0][0]
+    assert 0 < first[..., 4].sum() < final[..., 4].sum() * 0.9      # taken while the render was running
+    with gpu.Context(device=0, seed=5).upload(sc) as ctx:
+        ref, _ = ctx.render(32)
+    np.testing.assert_allclose(final, ref, rtol=1e-4, atol=1e-5)
