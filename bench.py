@@ -13,12 +13,19 @@ rendering) and every rank renders N x spp of its tiles, so per-GPU work is const
 films are merged by one RCCL sum-reduce per step (what Film::put(block) does in the reference), inside the
 timed region.  --split sample renders the whole frame on every rank with disjoint sample ranges instead.
 
-Roofline (dominant kernel): `achieved` = algorithmic bytes per launch (rays x (io + nodes/ray x
-node bytes + tris/ray x triangle bytes), the per-ray counts measured by a counting pass of the same
-traversal in this run) / the HIP-event launch duration measured in this run, against the 8 TB/s HBM peak;
-`traffic` = HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (used only when
-they were taken on this workload with this batch size).  Cache-resident workloads (C1-C3) can exceed the
-HBM peak in algorithmic bytes; their line then reports against the L2 gather ceiling and says so.
+Roofline (dominant kernel = the kernel stage with the largest exclusive time): ONE object, every use figure <= 1 by
+construction, all of it reproducible from profiles/:
+  valu_issue.frac = time the chip's 1024 SIMDs need to ISSUE the kernel's VALU instructions / the launch duration measured in
+      this run -- instructions per launch from PMC SQ_INSTS_VALU (profiles/pmc_traffic.json), weighted class by class
+      (profiles/r3_isa_classes.json: instruction mix of the traversal loop) with the issue rates tests/tools/valu_peak.hip
+      measured on this chip (profiles/valu_peak_gfx950.txt);
+  hbm.frac        = HBM bytes per launch from the PMC passes ((2 x FETCH_SIZE + WRITE_SIZE) x 1024, gfx950 correction of
+      MI355X_MICROARCH.md) / duration / 8 TB/s;
+  bound / achieved / peak / frac = the larger of the two, named.
+  algorithmic_gbps = SURVEY 8d's accounting figure (rays x (io + nodes/ray x node bytes + tris/ray x triangle bytes), the
+      per-ray counts measured by a counting pass of the same traversal in this run) / duration.  It prices every node and
+      triangle visit as if it came from HBM; the caches serve most of them, so it exceeds the HBM peak by design and has NO
+      peak attached.
 """
 import argparse
 import ctypes
@@ -33,10 +40,26 @@ sys.path.insert(0, os.path.join(ROOT, "ray-tracer_amd"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
-# MI355X_MICROARCH.md, 'Indexed rows: gather': chip-wide rates of divergent row gathers by where the rows are served from
-# VALU issue peak: 256 CUs x 4 SIMDs, one wave64 VALU instruction per SIMD every 4 cycles (16 lanes), 2.4 GHz
-VALU_ISSUE_PEAK_PER_S = 256 * 4 * 2.4e9 / 4
-GATHER_CEILINGS_GBS = {"l2_resident_rows": 17800.0, "infinity_cache_random_rows": 8600.0, "beyond_infinity_cache_random_rows": 5600.0}
+# unit of the issue rates in profiles/valu_peak_gfx950.txt: wave64 VALU instructions per SIMD per 4 cycles at 2.4 GHz, 256 CUs x 4 SIMDs
+VALU_SLOTS_PER_S = 256 * 4 * 2.4e9 / 4
+
+
+def load_valu_model(stage):
+    """-> (seconds the chip needs to issue ONE wave-level VALU instruction of this stage's mix, detail) from the committed
+    microbenchmark rates and the loop's instruction mix; None when either file is missing"""
+    import re
+    try:
+        rates = {}
+        for line in open(os.path.join(ROOT, "profiles", "valu_peak_gfx950.txt")):
+            m = re.match(r"(.{18})\s+[\d.]+ ms\s+[\d.e+]+ wave-instructions/s\s+=\s+([\d.]+) per SIMD", line)
+            if m:
+                rates[m.group(1).strip()] = float(m.group(2))
+        mix = json.load(open(os.path.join(ROOT, "profiles", "r3_isa_classes.json")))[stage]["share_by_kind"]
+        slots = sum(share / rates[kind] for kind, share in mix.items())       # SIMD issue slots (4 cycles) per instruction of the mix
+        return slots / VALU_SLOTS_PER_S, {"issue_slots_per_instruction": round(slots, 4), "mix": mix,
+                                          "rates_per_simd_per_4_cycles": {k: rates[k] for k in mix}}
+    except Exception:
+        return None
 
 
 def make_workload(name, scale):
@@ -255,7 +278,6 @@ def measure_roofline(ctx, scene, args, kw, n_b, n_l, spp, film, stats, elapsed, 
     launches = max(1, stage_n[dom])
     avg_launch_s = max(stage_s[dom] / launches, 1e-12)
     alg_per_launch = bytes_k[dom] / launches
-    achieved = alg_per_launch / avg_launch_s / 1e9
     ray_class = {0: 0, 2: 1, 3: 2}.get(dom)
     rays_per_launch = None if ray_class is None else sum(s.class_rays[ray_class] for s in xstats) / launches
     samples_per_batch = sum(s.samples for s in xstats) / max(1, stage_n[1])      # kShade runs once per batch
@@ -264,41 +286,47 @@ def measure_roofline(ctx, scene, args, kw, n_b, n_l, spp, film, stats, elapsed, 
     per_batch = launches / max(1, stage_n[1])
     kernel_note = {"bsdf": "bsdf = kTraceRound<closest> + kTraceTail<closest> (%d rounds = %d launches per batch of rays, averaged)" % (per_batch, per_batch),
                    "shadow": "shadow = kTraceRound<any> + kTraceTail<any> (%d rounds = %d launches per batch of rays, averaged)" % (per_batch, per_batch)}
-    valu = None if pmc is None or not pmc.get("valu_insts_per_launch") else pmc["valu_insts_per_launch"] / avg_launch_s / VALU_ISSUE_PEAK_PER_S
-    hbm_frac = achieved / HBM_PEAK_GBS
-    r = {"bound": "hbm", "kernel": kernel_note.get(name, name), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "frac": round(hbm_frac, 5), "traffic": traffic}
-    if hbm_frac > 1.0:
-        # more algorithmic bytes per second than HBM can deliver: the visits are served by L1 / L2 / Infinity Cache, an HBM
-        # fraction is meaningless here; report against the guide's L2-resident gather rate instead and say so
-        peak = GATHER_CEILINGS_GBS["l2_resident_rows"]
-        r.update({"bound": "l2-gather (cache-resident tree: algorithmic bytes exceed the HBM peak)", "peak": peak, "frac": round(achieved / peak, 5)})
-    r.update({
-        # the measured HBM side of the same kernel (PMC: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, gfx950 correction of
-        # MI355X_MICROARCH.md; FETCH_SIZE includes Infinity-Cache hits, so this is an upper bound of the DRAM traffic)
-        "hbm_measured_gbps": None if traffic is None else round(traffic / avg_launch_s / 1e9, 2),
-        "hbm_measured_frac": None if traffic is None else round(traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS, 5),
-        "l2_hit_rate": None if pmc is None else pmc.get("l2_hit_rate"),
-        # what actually binds the traversal kernels: wave-level VALU instructions per launch (PMC SQ_INSTS_VALU) / this run's launch
-        # duration / the chip's VALU issue peak
-        "valu_issue_util": None if valu is None else round(valu, 4),
-        "binds": None if valu is None else ("VALU issue" if valu > max(0.6, (traffic or 0) / avg_launch_s / 1e9 / HBM_PEAK_GBS) else "memory"),
-        "pmc_source": None if pmc is None else "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, same workload and batch size)",
-        "algorithmic_vs_gather_ceilings": {k: round(achieved / v, 4) for k, v in GATHER_CEILINGS_GBS.items()},
-        "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": stage_n[dom], "rays_per_launch": None if rays_per_launch is None else round(rays_per_launch), "samples_per_batch": round(samples_per_batch),
-        "measured": "one-lane pass (KKD_FLAG_ONE_LANE) of the same render inside this run, %d steps: exclusive kernel durations" % x_steps,
-        "avg_launch_ms_timed_region": round(shared_s[dom] / max(1, shared_n[dom]) * 1e3, 4),
-        "one_lane_ms_per_step": round(one_lane_ms, 3),
-        "algorithmic_bytes_per_launch": round(alg_per_launch),
-        "nodes_per_ray": [round(p[0], 2) for p in per_ray], "tris_per_ray": [round(p[1], 2) for p in per_ray],
-        "node_bytes": acc["node_bytes"], "tri_bytes": acc["tri_bytes"],
-        # whole job: algorithmic bytes of all five stages per second of the timed region, and the
-        # compulsory lower bound (scene structures read once + film written once) the re-reads are measured against
-        "job_algorithmic_gbps": round(sum(sum(stage_bytes(s_, n_b, n_l, per_ray, acc["node_bytes"], acc["tri_bytes"])) for s_ in stats) / elapsed / 1e9, 2),
-        "compulsory_bytes_per_step": int(acc["n_nodes"] * (acc["node_bytes"] + 128) + acc["n_leaf_tris"] * acc["tri_bytes"]
-                                         + scene._nv * (12 + 12 + 8) + scene._nt * 12 + W * H * 5 * 4),
-        "stage_ms_per_step": {abi.STAGE_NAMES[k]: round(stage_s[k] / x_steps * 1e3, 3) for k in range(5)},
-        "stage_ms_per_step_timed_region": {abi.STAGE_NAMES[k]: round(shared_s[k] / args.steps * 1e3, 3) for k in range(5)}})
+    alg_gbps = alg_per_launch / avg_launch_s / 1e9
+    hbm = None
+    if traffic is not None:
+        g = traffic / avg_launch_s / 1e9
+        hbm = {"achieved": round(g, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(g / HBM_PEAK_GBS, 5), "bytes_per_launch": traffic,
+               "l2_hit_rate": pmc.get("l2_hit_rate"),
+               "source": "PMC (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch, profiles/pmc_traffic.json; FETCH_SIZE includes Infinity-Cache hits: an upper bound of the DRAM traffic"}
+    valu = None
+    model = load_valu_model(name) if pmc is not None and pmc.get("valu_insts_per_launch") else None
+    if model is not None:
+        sec_per_inst, detail = model
+        n = pmc["valu_insts_per_launch"]
+        t_issue = n * sec_per_inst
+        valu = {"achieved": round(n / avg_launch_s / 1e9, 2), "peak": round(1.0 / sec_per_inst / 1e9, 2), "unit": "G wave-instructions/s",
+                "frac": round(t_issue / avg_launch_s, 5), "valu_instructions_per_launch": n,
+                "issue_time_ms_per_launch": round(t_issue * 1e3, 4), **detail,
+                "source": "PMC SQ_INSTS_VALU per launch (profiles/pmc_traffic.json) x the loop's instruction mix (profiles/r3_isa_classes.json) / the per-class issue rates measured by tests/tools/valu_peak.hip (profiles/valu_peak_gfx950.txt)"}
+    # the bound is the resource in larger use; both fractions are <= 1 by construction
+    if valu is not None and (hbm is None or valu["frac"] >= hbm["frac"]):
+        top = {"bound": "valu-issue", "achieved": valu["achieved"], "peak": valu["peak"], "unit": valu["unit"], "frac": valu["frac"]}
+    elif hbm is not None:
+        top = {"bound": "hbm", "achieved": hbm["achieved"], "peak": hbm["peak"], "unit": hbm["unit"], "frac": hbm["frac"]}
+    else:
+        top = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None}
+    r = {**top, "kernel": kernel_note.get(name, name), "traffic": traffic, "valu_issue": valu, "hbm": hbm,
+         "pmc_source": None if pmc is None else "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, same workload and batch size)",
+         # SURVEY 8d's accounting figure: no peak attached (cache-served visits priced as HBM bytes; exceeds the HBM peak by design)
+         "algorithmic_gbps": round(alg_gbps, 2), "algorithmic_bytes_per_launch": round(alg_per_launch),
+         "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": stage_n[dom], "rays_per_launch": None if rays_per_launch is None else round(rays_per_launch), "samples_per_batch": round(samples_per_batch),
+         "measured": "one-lane pass (KKD_FLAG_ONE_LANE) of the same render inside this run, %d steps: exclusive kernel durations" % x_steps,
+         "avg_launch_ms_timed_region": round(shared_s[dom] / max(1, shared_n[dom]) * 1e3, 4),
+         "one_lane_ms_per_step": round(one_lane_ms, 3),
+         "nodes_per_ray": [round(p[0], 2) for p in per_ray], "tris_per_ray": [round(p[1], 2) for p in per_ray],
+         "node_bytes": acc["node_bytes"], "tri_bytes": acc["tri_bytes"],
+         # whole job: algorithmic bytes of all five stages per second of the timed region, and the
+         # compulsory lower bound (scene structures read once + film written once) the re-reads are measured against
+         "job_algorithmic_gbps": round(sum(sum(stage_bytes(s_, n_b, n_l, per_ray, acc["node_bytes"], acc["tri_bytes"])) for s_ in stats) / elapsed / 1e9, 2),
+         "compulsory_bytes_per_step": int(acc["n_nodes"] * (acc["node_bytes"] + 128) + acc["n_leaf_tris"] * acc["tri_bytes"]
+                                          + scene._nv * (12 + 12 + 8) + scene._nt * 12 + W * H * 5 * 4),
+         "stage_ms_per_step": {abi.STAGE_NAMES[k]: round(stage_s[k] / x_steps * 1e3, 3) for k in range(5)},
+         "stage_ms_per_step_timed_region": {abi.STAGE_NAMES[k]: round(shared_s[k] / args.steps * 1e3, 3) for k in range(5)}}
     return r
 
 
@@ -321,17 +349,32 @@ def secondary_c2(device, proj):
             "ms_per_step": round(dt / 5 * 1e3, 3), "mrays_per_s": round(sum(s.rays_closest + s.rays_shadow for s in st) / dt / 1e6, 3)}
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(scene, n_b, n_l, W, H):
     """The oracle (CPU restatement of the reference path: SAH kd-tree + TriAccel + Havran + kk Li, 32x32 tiles,
     one thread per core) timed on a bounded sample of the same workload: the full frame at a low spp."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import kkoracle
-    cores = min(16, os.cpu_count() or 1)
+    cores = min(16, os.cpu_count() or 1)      # the box's CPU share for one GPU (gpurun sets OMP_NUM_THREADS etc. to 16); os.cpu_count() is the whole machine
     o = kkoracle.Oracle(scene)
     _, s1 = o.render(1, n_b, n_l, threads=cores)
     spp = int(max(1, min(64, 12.0 / max(s1.seconds, 1e-3))))
     _, st = o.render(spp, n_b, n_l, threads=cores)
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except Exception:
+        affinity = None
     return {"value": round(st.samples / st.seconds / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "host_logical_cpus": os.cpu_count(), "host_cpus_in_affinity_mask": affinity, "host_cpu_model": _cpu_model(),
             "mrays_per_s": round((st.rays_closest + st.rays_shadow) / st.seconds / 1e6, 3),
             "sample": "same scene and resolution (%dx%d) at %d spp instead of the workload's spp, %.1f s of CPU time" % (W, H, spp, st.seconds)}
 

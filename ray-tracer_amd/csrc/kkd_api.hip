@@ -41,6 +41,7 @@ struct DevBuf {
 } /* namespace */
 
 static constexpr int kMaxLanes = 4;
+static constexpr size_t kMemHeadroom = 768ull << 20;   /* device memory a render leaves free for the runtime's own allocations */
 
 /* ---- scratch of the entry point that allocates nothing (kkd_trace_device_noalloc) ----------------------------------
  * The sharded ray / traversal counters of a trace launch (kCounterShards lines of 128 bytes = 128 KiB), which the other
@@ -643,6 +644,13 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
             needL(ctx->pShadowRays, S * sizeof(DRay)); needL(ctx->pLrec, S * 16); needL(ctx->pSampleIdx, 2 * S * sizeof(uint32_t));
         }
         if (!devFilm) need(ctx->film, (size_t)W * H * 5 * sizeof(float));
+        if (e == hipSuccess) {
+            /* The buffers fit -- but a device left with next to nothing cannot run them: the runtime allocates the kernels'
+             * private segments (the spilled part of the traversal stack, ~0.2 GB when the chip is full of waves) when they
+             * are dispatched, and a failure THERE aborts the queue and the process.  Keep kMemHeadroom free. */
+            size_t freeB = 0, totalB = 0;
+            if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB < kMemHeadroom && (batch > (1ull << 20) || envLanes > 1)) e = hipErrorOutOfMemory;
+        }
         if (e == hipSuccess) break;
         if (e != hipErrorOutOfMemory) return fail(ctx, KKD_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
         (void)hipGetLastError();
@@ -650,6 +658,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         DevBuf *work[] = { &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->contRecs, &ctx->contStacks, &ctx->contCount,
                            &ctx->shadowRays, &ctx->occluded, &ctx->lrec, &ctx->pathAlive, &ctx->pBsdfRays, &ctx->pBrec, &ctx->pRefN, &ctx->pShadowRays, &ctx->pLrec, &ctx->pSampleIdx };
         for (DevBuf *b : work) b->release();
+        if (getenv("KKD_VERBOSE")) fprintf(stderr, "kkd_render: out of device memory with %llu samples in flight on %d lane(s): backing off\n", (unsigned long long)batch, nLanes);
         if (batch > (1ull << 20)) batchCap = std::max<uint64_t>(1ull << 20, batch / 2);
         else if (envLanes > 1) envLanes = 1;
         else return fail(ctx, KKD_ERR_NOMEM, "hipMalloc: out of memory for the wavefront buffers of 1 M samples in flight");

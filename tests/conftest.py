@@ -30,3 +30,14 @@ def gpu():
     if kkdirect.device_count() < 1:
         pytest.fail("GPU test on a machine without a HIP device (libkkdirect has no CPU fallback)")
     return kkdirect
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """measured same-stream relMSE values of the GPU image tests -> gpurun_out/parity_same_stream.json (the bounds of those tests are
+    set from these; profiles/ holds the committed copy)"""
+    import json
+    import helpers
+    if helpers.MEASURED:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "parity_same_stream.json"), "w") as f:
+            json.dump(helpers.MEASURED, f, indent=1, sort_keys=True)

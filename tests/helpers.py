@@ -9,6 +9,16 @@ def rel_mse(img, ref, eps=1e-3):
     return float(((img - ref) ** 2 / (ref ** 2 + eps)).mean())
 
 
+MEASURED = {}      # same-sample-stream relMSE per test, written to gpurun_out/parity_same_stream.json when the session ends (conftest.py)
+
+
+def record_parity(value, tol):
+    """keeps the measured relMSE of the running test beside its bound, so that the bounds can be held against measurements"""
+    import os
+    name = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    MEASURED.setdefault(name, []).append({"relmse": float(value), "bound": float(tol)})
+
+
 def develop(film):
     w = film[..., 4:5]
     return np.where(w > 0, film[..., :3] / np.maximum(w, 1e-30), 0.0)

@@ -26,11 +26,10 @@ def test_bench_line_has_the_contract_fields():
     r = j["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
-    # a fraction of a roofline is at most 1: against the HBM peak, or -- when a cache-resident tree serves more algorithmic
-    # bytes per second than HBM could -- against the L2 gather ceiling, named as such
-    assert r["unit"] == "GB/s" and (r["bound"] == "hbm" and r["peak"] == 8000.0 or r["bound"].startswith("l2-gather") and r["peak"] > 8000.0)
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] <= 1.0
-    assert r["traffic"] is None          # no PMC summary matches this reduced configuration: nothing is borrowed from another run
+    # no PMC summary matches this reduced configuration, and nothing is borrowed from another run: the use figures stay empty, the
+    # accounting figure (no peak attached) and the measured durations are there
+    assert r["traffic"] is None and r["frac"] is None and r["valu_issue"] is None and r["hbm"] is None
+    assert r["algorithmic_gbps"] > 0
     assert r["avg_launch_ms"] > 0 and r["launches"] > 0 and sum(r["stage_ms_per_step"].values()) > 0
 
 
@@ -63,3 +62,20 @@ def test_single_process_multi_device_bench_path():
     else:
         j = json.loads(out.stdout.splitlines()[-1])
         assert j["n_gpus"] == 2 and "in-library" in j["config"]["multi_gpu"]
+
+
+def test_roofline_inputs_are_committed_and_consistent():
+    """CPU: what the headline line's roofline is computed from -- the measured issue rates, the loop's instruction mix and the PMC
+    summary of the headline workload -- is in profiles/, parses, and yields use figures in (0, 1]"""
+    sys.path.insert(0, ROOT)
+    import bench
+    for stage in ("bsdf", "shadow"):
+        model = bench.load_valu_model(stage)
+        assert model is not None, "profiles/valu_peak_gfx950.txt or profiles/r3_isa_classes.json missing"
+        sec, detail = model
+        assert 0.5 < detail["issue_slots_per_instruction"] < 2.5 and abs(sum(detail["mix"].values()) - 1) < 1e-2
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["c4"]
+    assert abs(pmc["samples_per_batch"] - 3840 * 2160 * 512 / 64) < 0.02 * pmc["samples_per_batch"]      # the headline's batch size
+    for stage in ("bsdf", "shadow"):
+        st = pmc["stages"][stage]
+        assert st["valu_insts_per_launch"] > 0 and st["hbm_bytes_per_launch"] > 0

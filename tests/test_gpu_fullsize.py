@@ -79,6 +79,7 @@ def _crop_parity(gpu, sc, crop, spp, tol, **kw):
     assert sg.samples == so.samples == crop[2] * crop[3] * spp
     assert np.isfinite(film).all() and film.min() >= 0
     r = helpers.rel_mse(helpers.develop(film), helpers.develop(ref))
+    helpers.record_parity(r, tol)
     assert r < tol, r
     return r
 
@@ -119,13 +120,15 @@ def test_full_size_c3_many_lights(gpu, record_property):
     report = []
     _hit_id_bar(gpu, sc, o, _ray_sets(o, sc, 300_000, seed=2), report)
     print("\\n".join(report))
-    r = _crop_parity(gpu, sc, (832, 476, 256, 128), 16, 5e-4)
+    # measured 6.2e-11 with no flipped sample (profiles/parity_r3.json) and 8e-7 on the single-mesh variant below (profiles/
+    # parity_same_stream_r3.json; one sample that takes another branch on a last-bit difference costs ~1e-7 to 1e-6): 12x measured
+    r = _crop_parity(gpu, sc, (832, 476, 256, 128), 16, 1e-5)
     record_property("crop_relmse", r)
     with gpu.Context(device=0, seed=1).upload(sc) as ctx:
         _frame_properties(ctx, 1920, 1080, 128)
     # the variant with ONE emissive mesh of 10 000 triangles (TriMesh area CDF, librender/trimesh.cpp:392-407)
     sc1 = scenes.many_lights(1920, 1080, interior_tris=260_000, single_mesh=True)
-    _crop_parity(gpu, sc1, (832, 476, 256, 128), 16, 5e-4)
+    _crop_parity(gpu, sc1, (832, 476, 256, 128), 16, 1e-5)
 
 
 _C4 = {}
@@ -150,7 +153,10 @@ def test_full_size_c4_scanned_mesh(gpu, record_property):
     _hit_id_bar(gpu, sc, o, _ray_sets(o, sc, 300_000, seed=3, chord_n=200_000), report, watertight_bounds=(4e-4, 2e-3))
     print("\\n".join(report))
     record_property("hit_id_report", report)
-    r = _crop_parity(gpu, sc, (1792, 1016, 256, 128), 16, 1e-3)
+    # measured 6.7e-7, ALL of it from 273 of 524 288 samples (5e-4) that take another branch on a last-bit difference -- a hit
+    # across an edge of the sub-pixel triangles, the lobe a sample picks, a Newton step -- and are then different, equally valid
+    # samples under the 1e4 suns; without them 2.7e-11 (profiles/parity_r3.json classifies the 20 worst pixels): 15x measured
+    r = _crop_parity(gpu, sc, (1792, 1016, 256, 128), 16, 1e-5)
     record_property("crop_relmse", r)
     with gpu.Context(device=0, seed=1).upload(sc) as ctx:
         info = ctx.accel_info()

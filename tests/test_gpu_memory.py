@@ -10,19 +10,21 @@ from kkdirect import scenes
 pytestmark = pytest.mark.gpu
 
 
-def test_render_backs_off_under_memory_pressure(gpu):
+def test_render_backs_off_under_memory_pressure(gpu, capfd, monkeypatch):
+    monkeypatch.setenv("KKD_VERBOSE", "1")
     sc = scenes.sponza_class(1280, 720, target_tris=60_000)
     with gpu.Context(device=0, seed=3).upload(sc) as ctx:
         ref, st = ctx.render(16)
     torch.cuda.empty_cache()
     with gpu.Context(device=0, seed=3).upload(sc) as ctx:
         free, _ = torch.cuda.mem_get_info()
-        keep = 1 << 30                                            # what the render may still take: 1 GiB (it wants ~6 GB)
+        keep = 3 << 30                                            # what the render may still take: 3 GiB (it wants ~4 GB and must leave 0.75 GB)
         hog = torch.empty(max(0, free - keep), dtype=torch.uint8, device="cuda")
         try:
             film, s2 = ctx.render(16)
         finally:
             del hog
             torch.cuda.empty_cache()
+    assert "backing off" in capfd.readouterr().err           # the render did run out of memory first
     assert s2.samples == st.samples and s2.rays_closest == st.rays_closest and s2.rays_shadow == st.rays_shadow
     np.testing.assert_allclose(film, ref, rtol=1e-4, atol=1e-5)

@@ -66,6 +66,15 @@ __global__ void __launch_bounds__(256) k(float *out, int iters, float a, float b
         } else if (KIND == 17) {
 #define MED3(x) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));
             REP8(MED3) REP8(MED3)
+        } else if (KIND == 19) {
+#define FMX(x) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(x) : "v"(u0), "v"(a));
+            REP8(FMX) REP8(FMX)
+        } else if (KIND == 20) {
+#define BFE(x) asm volatile("v_bfe_u32 %0, %1, 5, 3" : "=v"(x) : "v"(u0));
+            REP8(BFE) REP8(BFE)
+        } else if (KIND == 21) {
+#define MULLO(x) asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(x) : "v"(u0), "v"(u0));
+            REP8(MULLO) REP8(MULLO)
         } else if (KIND == 18) {
 #define CNDV(x) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(a) : "vcc");
             REP8(CNDV)
@@ -93,5 +102,6 @@ int main() {
     run<7>("v_cndmask_e64 sgpr", out, blocks); run<8>("v_min_f32", out, blocks); run<9>("v_sub_f32", out, blocks); run<10>("v_cmp_lt_f32_e64", out, blocks);
     run<11>("v_and_b32", out, blocks); run<12>("v_mov_b32", out, blocks); run<13>("v_min_u32", out, blocks); run<14>("v_perm_b32", out, blocks);
     run<15>("v_lshl_or_b32", out, blocks); run<16>("v_add_u32", out, blocks); run<17>("v_med3_f32", out, blocks); run<18>("cmp+cndmask pair", out, blocks);
+    run<19>("v_fma_mix_f32", out, blocks); run<20>("v_bfe_u32", out, blocks); run<21>("v_mul_lo_u32", out, blocks);
     return 0;
 }
