@@ -198,6 +198,8 @@ static bool kkdRenderOnGpu(Scene *scene, RenderQueue *queue, const RenderJob *jo
         /* halton: deterministic; its 'scramble' is not readable from outside the plugin: the default, -1 (Faure permutations) */
         else if (scene->getSampler()->getClass()->getName() == "HaltonSampler") rp.sampler = KKD_SAMPLER_HALTON;
         else if (scene->getSampler()->getClass()->getName() == "HammersleySampler") rp.sampler = KKD_SAMPLER_HAMMERSLEY;
+        /* sobol: deterministic with its default scramble = 0 (samplers/sobol.cpp:93); a scrambled one cannot be told apart from outside */
+        else if (scene->getSampler()->getClass()->getName() == "SobolSampler") rp.sampler = KKD_SAMPLER_SOBOL;
         else if (scene->getSampler()->getClass()->getName() != "IndependentSampler")
             SLog(EWarn, "kkIntegrator: sampler \"%s\" is not available on the GPU path, using independent samples", scene->getSampler()->getClass()->getName().c_str());
         ref<ImageBlock> block = new ImageBlock(Bitmap::ESpectrumAlphaWeight, film->getCropSize(), NULL);

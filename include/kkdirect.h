@@ -249,6 +249,10 @@ typedef struct kkd_render_params {
 #define KKD_SAMPLER_HALTON_PLAIN 4u  /* halton plugin with scramble = 0: plain radical inverses           */
 #define KKD_SAMPLER_HAMMERSLEY  5u   /* hammersley plugin, scramble = -1 (its default)                    */
 #define KKD_SAMPLER_HAMMERSLEY_PLAIN 6u /* hammersley plugin, scramble = 0                                */
+#define KKD_SAMPLER_SOBOL       7u   /* sobol plugin (samplers/sobol.cpp:82-279), scramble = 0 (its default): Joe and Kuo's direction numbers for
+                                        1024 dimensions (samplers/sobolseq.cpp); the first two dimensions address the pixel through
+                                        sobol::look_up (sobolseq.h:102-137) on a 2^m x 2^m grid covering the film, sample arrays take dimensions
+                                        5, 6 (7, 8); deterministic, so the values ARE the reference's */
 #define KKD_INTEGRATOR_KK     0u
 #define KKD_INTEGRATOR_DIRECT 1u
 #define KKD_INTEGRATOR_PATH   2u
@@ -383,6 +387,11 @@ int kkd_probe_halton(uint32_t res_x, uint32_t res_y, int32_t x, int32_t y, int f
 /* The Faure permutation of `base` (2 ... 8161) as PermutationStorage::computeFaurePermutations builds it (samplers/faure.cpp:101-131);
  * out: base entries. */
 int kkd_probe_faure_permutation(uint32_t base, uint16_t *out);
+/* The sobol sampler on the host, for tests (samplers/sobol.cpp:158-262 on a res_x x res_y film; arguments as kkd_probe_halton,
+ * faure unused), and its two building blocks: sobol::sampleSingle(index, dim) as its 32 result bits, sobol::look_up(m, frame, px,
+ * py, 0) (samplers/sobolseq.h:43-60, 102-137); crc32 (optional) receives the CRC-32 of the regenerated 1024 x 52 matrix words. */
+int kkd_probe_sobol(uint32_t res_x, uint32_t res_y, int32_t x, int32_t y, int kind, uint32_t dim, uint32_t array_n, uint32_t n_arrays, uint32_t count, float *out);
+int kkd_probe_sobol_raw(uint64_t index, uint32_t dim, uint32_t m, uint32_t frame, uint32_t px, uint32_t py, uint32_t *sample_bits, uint64_t *look_up_index, uint32_t *crc32);
 
 /* ---- film develop and output: the step right after the path ---- */
 

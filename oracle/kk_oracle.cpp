@@ -145,6 +145,19 @@ void ora_halton(uint32_t resX, uint32_t resY, int32_t x, int32_t y, int faure, i
         else for (uint32_t e = 0; e < arrayN; ++e) { V2 v = s.next2DArray(dim, arrayN, e); out[2 * ((size_t)j * arrayN + e)] = v.x; out[2 * ((size_t)j * arrayN + e) + 1] = v.y; }
     }
 }
+/* sobol sampler, arguments as ora_halton; and its building blocks: sampleSingle's 32 bits, look_up's index */
+void ora_sobol(uint32_t resX, uint32_t resY, int32_t x, int32_t y, int kind, uint32_t dim, uint32_t arrayN, uint32_t nArrays, uint32_t count, float *out) {
+    SobolCfg cfg; cfg.setFilmResolution((int)resX, (int)resY, nArrays);
+    for (uint32_t j = 0; j < count; ++j) {
+        SampleStream s(0, 0, j);
+        s.useSobol(&cfg, x, y); s.hdim = dim;
+        if (kind == 0) { V2 v = s.next2D(); out[2 * j] = v.x; out[2 * j + 1] = v.y; }
+        else if (kind == 1) out[j] = s.next1D();
+        else for (uint32_t e = 0; e < arrayN; ++e) { V2 v = s.next2DArray(dim, arrayN, e); out[2 * ((size_t)j * arrayN + e)] = v.x; out[2 * ((size_t)j * arrayN + e) + 1] = v.y; }
+    }
+}
+uint32_t ora_sobol_bits(uint64_t index, uint32_t dim) { return SobolCfg::bits(index, dim); }
+uint64_t ora_sobol_look_up(uint32_t m, uint32_t frame, uint32_t px, uint32_t py) { return SobolCfg::lookUp(m, frame, px, py); }
 void ora_clip_aabb(const float *tri9, const float *box6, float *out6) {
     AABB b(V3(box6[0], box6[1], box6[2]), V3(box6[3], box6[4], box6[5]));
     AABB r = triClippedAABB(V3(tri9[0], tri9[1], tri9[2]), V3(tri9[3], tri9[4], tri9[5]), V3(tri9[6], tri9[7], tri9[8]), b);

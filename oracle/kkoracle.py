@@ -46,6 +46,10 @@ def lib():
         L.ora_stratified.restype = None
         L.ora_halton.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, abi.pf32]
         L.ora_halton.restype = None
+        L.ora_sobol.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, abi.pf32]
+        L.ora_sobol.restype = None
+        L.ora_sobol_bits.argtypes = [C.c_uint64, C.c_uint32]; L.ora_sobol_bits.restype = C.c_uint32
+        L.ora_sobol_look_up.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]; L.ora_sobol_look_up.restype = C.c_uint64
         L.ora_clip_aabb.argtypes = [abi.pf32, abi.pf32, abi.pf32]
         L.ora_bsdf_eval.argtypes = [C.c_void_p, C.c_int, abi.pf32, abi.pf32, abi.pf32, abi.pf32]
         L.ora_bsdf_sample.argtypes = [C.c_void_p, C.c_int, abi.pf32, abi.pf32, C.c_uint64, abi.pf32]
@@ -194,6 +198,21 @@ def stratified(seed, pixel, kind, index, array_n, res, flat_dim, count):
     out = np.zeros(count * (1 if kind == 1 else 2 * (array_n if kind == 2 else 1)), np.float32)
     lib().ora_stratified(seed, pixel, kind, index, array_n, res, flat_dim, count, _fp(out))
     return out if kind == 1 else out.reshape((count, 2) if kind == 0 else (count, array_n, 2))
+
+
+def sobol(res_x, res_y, x, y, kind, dim, array_n, n_arrays, count):
+    """sobol sampler, shapes as halton()"""
+    out = np.zeros(count * (1 if kind == 1 else 2 * (array_n if kind == 2 else 1)), np.float32)
+    lib().ora_sobol(res_x, res_y, x, y, kind, dim, array_n, n_arrays, count, _fp(out))
+    return out if kind == 1 else out.reshape((count, 2) if kind == 0 else (count, array_n, 2))
+
+
+def sobol_bits(index, dim):
+    return int(lib().ora_sobol_bits(index, dim))
+
+
+def sobol_look_up(m, frame, px, py):
+    return int(lib().ora_sobol_look_up(m, frame, px, py))
 
 
 def halton(res_x, res_y, x, y, faure, kind, dim, array_n, n_arrays, count):

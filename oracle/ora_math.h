@@ -19,6 +19,7 @@
  */
 #pragma once
 #include <cmath>
+#include "../ray-tracer_amd/csrc/kkd_sobol_dirnums.h"   /* data only: Joe and Kuo's direction numbers */
 #include <cstdint>
 #include <cstring>
 #include <algorithm>
@@ -381,6 +382,68 @@ struct HaltonCfg {
     }
 };
 
+/* ---- sobol sampler (samplers/sobol.cpp:146-262, samplers/sobolseq.h:43-60, 102-137), scramble = 0 ----
+ * The generator matrices are regenerated from Joe and Kuo's direction numbers (the data header the library uses too; the code is
+ * the oracle's own).  look_up is answered by solving, for every call, the 2m x 2m system over GF(2) "which low index bits put the
+ * first two coordinates into pixel (px, py)" by elimination on the augmented matrix -- the library inverts the matrix once per
+ * render instead; both are pinned by the known answers of tests/golden/sobol_kat.json. */
+struct SobolCfg {
+    uint32_t m = 0, arrayEnd = 5; Float resolution = 1;
+    static const std::vector<uint32_t> &matrices() {
+        static const std::vector<uint32_t> t = [] {
+            std::vector<uint32_t> out(1024u * 52u, 0u);
+            const uint32_t *p = kkd::kJoeKuo;
+            for (uint32_t d = 0; d < 1024u; ++d) {
+                unsigned long long dir[52];
+                uint32_t s = 0, a = 0;
+                if (d == 0) { for (int k = 0; k < 52; ++k) dir[k] = 1ull; }                   /* van der Corput: m_k = 1 */
+                else { s = p[0]; a = p[1]; for (uint32_t k = 0; k < s; ++k) dir[k] = p[2 + k]; p += 2 + s; }
+                for (uint32_t k = d == 0 ? 52u : s; k < 52u; ++k) {
+                    unsigned long long v = dir[k - s] ^ (dir[k - s] << s);
+                    for (uint32_t i = 1; i < s; ++i) if ((a >> (s - 1 - i)) & 1u) v ^= dir[k - i] << i;
+                    dir[k] = v;
+                }
+                for (uint32_t k = 0; k < 52u; ++k) out[d * 52u + k] = (uint32_t)((dir[k] << (51u - k)) >> 20);
+            }
+            return out;
+        }();
+        return t;
+    }
+    void setFilmResolution(int resX, int resY, uint32_t nArrays) {               /* sobol.cpp:146-157, 173-179 */
+        uint32_t v = (uint32_t)std::max(1, std::max(resX, resY)), r = 1; m = 0;
+        while (r < v) { r <<= 1; ++m; }
+        resolution = (Float)r; arrayEnd = 5u + 2u * nArrays;
+    }
+    static uint32_t bits(uint64_t index, uint32_t dim) {                          /* sobolseq.h:43-57 */
+        const std::vector<uint32_t> &t = matrices(); uint32_t r = 0;
+        for (uint32_t i = dim * 52u; index; index >>= 1, ++i) if (index & 1u) r ^= t[i];
+        return r;
+    }
+    static Float value(uint64_t index, uint32_t dim) { const Float v = (Float)bits(index, dim) * 0x1p-32f; return v < 0x1.fffffep-1f ? v : 0x1.fffffep-1f; }
+    /* sobolseq.h:102-137: the index whose bits above 2m are `frame` and whose first two coordinates begin with px, py */
+    static uint64_t lookUp(uint32_t m, uint32_t frame, uint32_t px, uint32_t py) {
+        const uint64_t high = (uint64_t)frame << (2 * m);
+        auto top = [&](uint64_t index) { return ((uint64_t)(bits(index, 0) >> (32 - m)) << m) | (uint64_t)(bits(index, 1) >> (32 - m)); };
+        uint64_t want = (((uint64_t)px << m) | py) ^ top(high);
+        /* rows: one equation per bit of `want`; unknowns: the 2m low index bits.  eq[r] = coefficients | rhs << 2m */
+        const uint32_t n = 2 * m;
+        std::vector<uint64_t> eq(n, 0);
+        for (uint32_t i = 0; i < n; ++i) { const uint64_t c = top(1ull << i); for (uint32_t r = 0; r < n; ++r) if ((c >> r) & 1ull) eq[r] |= 1ull << i; }
+        for (uint32_t r = 0; r < n; ++r) if ((want >> r) & 1ull) eq[r] |= 1ull << n;
+        uint64_t low = 0;
+        for (uint32_t col = 0, row = 0; col < n; ++col) {
+            uint32_t p = row; while (p < n && !((eq[p] >> col) & 1ull)) ++p;
+            if (p == n) continue;
+            std::swap(eq[p], eq[row]);
+            for (uint32_t r = 0; r < n; ++r) if (r != row && ((eq[r] >> col) & 1ull)) eq[r] ^= eq[row];
+            ++row;
+        }
+        for (uint32_t r = 0; r < n; ++r) { const uint64_t coef = eq[r] & ((1ull << n) - 1); if (coef && ((eq[r] >> n) & 1ull)) low |= coef & (0 - coef); }
+        return high | low;
+    }
+    uint64_t index(int X, int Y, uint64_t j) const { return (m > 1 && X >= 0 && Y >= 0) ? lookUp(m, (uint32_t)j, (uint32_t)X, (uint32_t)Y) : j; }
+};
+
 /* One camera sample's Sampler: independent (samplers/independent.cpp:82-103) or ldsampler (samplers/ldsampler.cpp:148-229).
  * ldsampler: request k of the sample's 2D (1D) requests, k < ldDim, reads entry `sample` of the pixel's k-th scrambled and
  * shuffled (0,2)-sequence (van der Corput sequence); next2DArray(a, n, e) reads entry sample * n + e of requested array a; the
@@ -396,6 +459,8 @@ struct SampleStream {
     const HaltonCfg *hal = nullptr; int hX = 0, hY = 0;        /* halton: one running dimension hdim over the sample's requests (m_dimension) */
     uint32_t hdim = 0;
     void useHalton(const HaltonCfg *cfg, int X, int Y) { hal = cfg; hX = X; hY = Y; }
+    const SobolCfg *sob = nullptr;                             /* sobol: running dimension hdim, pixel hX, hY as for halton */
+    void useSobol(const SobolCfg *cfg, int X, int Y) { sob = cfg; hX = X; hY = Y; }
     uint64_t haltonIndex(uint64_t j) const { return hal->pixelOffset(HaltonCfg::tilePos(hX), HaltonCfg::tilePos(hY)) + hal->stride * j; }
     SampleStream(uint64_t seed, uint32_t pix, uint32_t smp)
         : pixel(pix), sample(smp), seedLo((uint32_t)seed), seedHi((uint32_t)(seed >> 32)), dim(0), cachedBlock(-1) {}
@@ -421,6 +486,11 @@ struct SampleStream {
     }
     Float next1D() {
         const uint32_t req = dim1D++;
+        if (sob) {                                                                   /* sobol.cpp:230-240 */
+            if (hdim >= 5 && hdim < sob->arrayEnd) hdim = sob->arrayEnd;
+            if (hdim < 1024) { dim += 1; return SobolCfg::value(sob->index(hX, hY, sample), hdim++); }
+            hdim += 1; return independent1D();                                       /* past the table: the reference stops with an error */
+        }
         if (hal) {                                                                   /* halton.cpp:352-362 */
             if (hdim >= 5 && hdim < hal->arrayEnd) hdim = hal->arrayEnd;
             if (hdim < 1024) { dim += 1; return hal->value(hdim++, haltonIndex(sample)); }
@@ -440,6 +510,18 @@ struct SampleStream {
     }
     V2 next2D() {
         const uint32_t req = dim2D++;
+        if (sob) {                                                                   /* sobol.cpp:242-262 */
+            if (hdim >= 5 && hdim < sob->arrayEnd) hdim = sob->arrayEnd;
+            if (hdim + 1 < 1024) {
+                dim += 2;
+                const uint64_t index = sob->index(hX, hY, sample);
+                const uint32_t d = hdim; hdim += 2;
+                const Float a = SobolCfg::value(index, d), b = SobolCfg::value(index, d + 1);
+                if (d == 0 && index != (uint64_t)sample) return V2{ a * sob->resolution - (Float)hX, b * sob->resolution - (Float)hY };
+                return V2{ a, b };
+            }
+            hdim += 2; Float a = independent1D(); Float b = independent1D(); return V2{ a, b };
+        }
         if (hal) {                                                                   /* halton.cpp:364-384 */
             if (hdim >= 5 && hdim < hal->arrayEnd) hdim = hal->arrayEnd;
             if (hdim + 1 < 1024) {
@@ -469,6 +551,11 @@ struct SampleStream {
     }
     /* element e of this sample's n-element slice of requested array `array` (Sampler::next2DArray, sampler.cpp:79-90) */
     V2 next2DArray(uint32_t array, uint32_t n, uint32_t e) {
+        if (sob) {                                                                   /* sobol.cpp:182-205: dimensions 5 + 2a, 6 + 2a */
+            dim += 2;
+            const uint64_t index = sob->index(hX, hY, (uint64_t)sample * n + e);
+            return V2{ SobolCfg::value(index, 5 + 2 * array), SobolCfg::value(index, 6 + 2 * array) };
+        }
         if (hal) {                                                                   /* halton.cpp:309-326: dimensions 5 + 2a, 6 + 2a */
             dim += 2;
             const uint64_t index = haltonIndex((uint64_t)sample * n + e);

@@ -515,11 +515,14 @@ struct RenderParams { uint32_t spp, nB, nL; bool hideEmitters; uint32_t blockSiz
                       uint32_t total() const { return sampleCountTotal ? sampleCountTotal : spp; }                /* Sampler::getSampleCount() */
                       static uint32_t pow2ceil(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
                       HaltonCfg halton;                                                                          /* filled by prepare() */
+                      SobolCfg sobol;
                       void prepare(int cropW, int cropH) {                                                       /* Integrator::configureSampler, integrator.cpp:37-41 */
                           if (sampler == KKD_SAMPLER_HAMMERSLEY || sampler == KKD_SAMPLER_HAMMERSLEY_PLAIN)
                               halton.setFilmResolutionHammersley(cropW, cropH, sampler == KKD_SAMPLER_HAMMERSLEY, total());
                           if (sampler == KKD_SAMPLER_HALTON || sampler == KKD_SAMPLER_HALTON_PLAIN)
                               halton.setFilmResolution(cropW, cropH, sampler == KKD_SAMPLER_HALTON, integrator == KKD_INTEGRATOR_PATH ? 0u : (nB > 1 ? 1u : 0u) + (nL > 1 ? 1u : 0u));
+                          if (sampler == KKD_SAMPLER_SOBOL)
+                              sobol.setFilmResolution(cropW, cropH, integrator == KKD_INTEGRATOR_PATH ? 0u : (nB > 1 ? 1u : 0u) + (nL > 1 ? 1u : 0u));
                       }
                       void configure(SampleStream &rng, int X, int Y) const {                                    /* ldsampler.cpp:76-87 */
                           if (sampler == KKD_SAMPLER_LDSAMPLER) rng.useLdSampler(pow2ceil(total()), samplerDimension ? samplerDimension : 4u);
@@ -528,6 +531,7 @@ struct RenderParams { uint32_t spp, nB, nL; bool hideEmitters; uint32_t blockSiz
                               rng.useStratified(res, samplerDimension ? samplerDimension : 4u);
                           }
                           if (sampler >= KKD_SAMPLER_HALTON && sampler <= KKD_SAMPLER_HAMMERSLEY_PLAIN) rng.useHalton(&halton, X, Y);
+                          if (sampler == KKD_SAMPLER_SOBOL) rng.useSobol(&sobol, X, Y);
                       } };
 struct Stats { std::atomic<uint64_t> samples{0}, raysClosest{0}, raysShadow{0}, nodes{0}, tris{0}; };
 

@@ -101,6 +101,7 @@ struct kkd_ctx {
      * events, a pinned host copy of the counter shards */
     /* tile sharding: this context's tiles (Morton round-robin), cached for the last (grid, index, count) */
     DevBuf haltonTables;       /* halton sampler: primes, offsets, Faure permutations (uploaded by the first render that uses it) */
+    DevBuf sobolTables; uint32_t sobolM = 0xFFFFFFFFu;   /* sobol sampler: generator matrices + the pixel look-up of resolution 2^sobolM */
     DevBuf tileList; std::vector<uint32_t> tileListHost; uint32_t tileKey[4] = { 0, 0, 0, 0 };
     void *noallocScratch = nullptr;
     hipEvent_t traceEv[2] = { nullptr, nullptr };
@@ -200,6 +201,38 @@ int kkd_probe_halton(uint32_t res_x, uint32_t res_y, int32_t x, int32_t y, int f
     return KKD_OK;
 }
 
+int kkd_probe_sobol(uint32_t res_x, uint32_t res_y, int32_t x, int32_t y, int kind, uint32_t dim, uint32_t array_n, uint32_t n_arrays, uint32_t count, float *out) {
+    if (!out || !res_x || !res_y || kind < 0 || kind > 2 || (kind == 2 && (!array_n || dim >= n_arrays)) || (kind != 2 && dim + (kind == 0 ? 1u : 0u) >= kSobolDimsMax)) return KKD_ERR_INVALID;
+    SobolSetup s; sobolSetup((int)res_x, (int)res_y, n_arrays, nullptr, s);
+    std::vector<uint32_t> words;
+    if (!sobolTables(s.m, words)) return KKD_ERR_UNSUPPORTED;
+    s.tables = words.data();
+    for (uint32_t j = 0; j < count; ++j) {
+        if (kind == 0) { const f2 v = sobolSample2D(s, x, y, j, sobolSkipArrays(s, dim)); out[2 * j] = v.x; out[2 * j + 1] = v.y; }
+        else if (kind == 1) out[j] = sobolSample1D(s, x, y, j, sobolSkipArrays(s, dim));
+        else for (uint32_t e = 0; e < array_n; ++e) {
+            const f2 v = sobolArray2D(s, x, y, dim, (uint64_t)j * array_n + e);
+            out[2 * ((size_t)j * array_n + e)] = v.x; out[2 * ((size_t)j * array_n + e) + 1] = v.y;
+        }
+    }
+    return KKD_OK;
+}
+
+int kkd_probe_sobol_raw(uint64_t index, uint32_t dim, uint32_t m, uint32_t frame, uint32_t px, uint32_t py, uint32_t *sample_bits, uint64_t *look_up_index, uint32_t *crc32) {
+    if (dim >= kSobolDimsMax || m > 20 || (m && (px >> m || py >> m))) return KKD_ERR_INVALID;
+    const std::vector<uint32_t> &mat = sobolMatrices();
+    if (crc32) *crc32 = crc32Words(mat.data(), mat.size());
+    if (sample_bits) { uint32_t r = 0; for (const uint32_t *c = mat.data() + (size_t)dim * kSobolColumns; index; index >>= 1, ++c) if (index & 1u) r ^= *c; *sample_bits = r; }
+    if (look_up_index) {
+        if (!m) return KKD_ERR_INVALID;
+        std::vector<uint32_t> words;
+        if (!sobolTables(m, words)) return KKD_ERR_UNSUPPORTED;
+        SobolSetup s; s.m = m; s.resolution = (float)(1u << m); s.arrayEnd = 5; s.pad = 0; s.tables = words.data();
+        *look_up_index = sobolLookUp(s, frame, px, py);
+    }
+    return KKD_OK;
+}
+
 int kkd_probe_faure_permutation(uint32_t base, uint16_t *out) {
     if (!out || base < 2) return KKD_ERR_INVALID;
     static const std::vector<uint32_t> tables = [] { std::vector<uint32_t> t; haltonTables(t); return t; }();
@@ -245,7 +278,7 @@ void kkd_destroy(kkd_ctx *ctx) {
                       &ctx->emitters, &ctx->emitterCdf, &ctx->areaCdf, &ctx->rtTables, &ctx->envTexels, &ctx->envCdfRows, &ctx->envCdfCols,
                       &ctx->envRowWeights, &ctx->contRecs, &ctx->contStacks, &ctx->contCount, &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->shadowRays,
                       &ctx->occluded, &ctx->lrec, &ctx->film, &ctx->counters, &ctx->apiRays, &ctx->apiHits,
-                      &ctx->envGuideRows, &ctx->envGuideCols, &ctx->emitterGuide, &ctx->areaGuide, &ctx->pathAlive, &ctx->pBsdfRays, &ctx->pBrec, &ctx->pRefN, &ctx->pShadowRays, &ctx->pLrec, &ctx->pSampleIdx, &ctx->tileList, &ctx->envEwaLut, &ctx->haltonTables };
+                      &ctx->envGuideRows, &ctx->envGuideCols, &ctx->emitterGuide, &ctx->areaGuide, &ctx->pathAlive, &ctx->pBsdfRays, &ctx->pBrec, &ctx->pRefN, &ctx->pShadowRays, &ctx->pLrec, &ctx->pSampleIdx, &ctx->tileList, &ctx->envEwaLut, &ctx->haltonTables, &ctx->sobolTables };
     for (DevBuf *b : all) b->release();
     for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->doneEvents) hipEventDestroy(ev);
@@ -544,7 +577,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     if (rp->spp == 0) return fail(ctx, KKD_ERR_INVALID, "spp must be positive");
     /* kk/direct.cpp:165-166 divides by both counts: zero is not a meaningful configuration */
     if (rp->integrator > KKD_INTEGRATOR_PATH) return fail(ctx, KKD_ERR_INVALID, "unknown integrator");
-    if (rp->sampler > KKD_SAMPLER_HAMMERSLEY_PLAIN) return fail(ctx, KKD_ERR_INVALID, "unknown sampler");
+    if (rp->sampler > KKD_SAMPLER_SOBOL) return fail(ctx, KKD_ERR_INVALID, "unknown sampler");
     if ((rp->sampler == KKD_SAMPLER_HAMMERSLEY || rp->sampler == KKD_SAMPLER_HAMMERSLEY_PLAIN) && rp->integrator != KKD_INTEGRATOR_PATH && (rp->bsdf_samples > 1 || rp->light_samples > 1))
         return fail(ctx, KKD_ERR_UNSUPPORTED, "request2DArray(): Not supported for the Hammersley QMC sequence!");   /* hammersley.cpp:299-303 */
     if (rp->sample_count_total && (uint64_t)rp->sample_first + rp->spp > rp->sample_count_total)
@@ -711,6 +744,19 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         /* Integrator::configureSampler (librender/integrator.cpp:37-41): the crop size, blocked; arrays as kk/direct.cpp:44-47 request them */
         if (rp->sampler >= KKD_SAMPLER_HAMMERSLEY) hammersleySetup(W, H, sampleCountTotal, rp->sampler == KKD_SAMPLER_HAMMERSLEY, (const uint32_t *)ctx->haltonTables.p, bp.halton);
         else haltonSetup(W, H, pathMode ? 0u : (nB > 1u ? 1u : 0u) + (nL > 1u ? 1u : 0u), rp->sampler == KKD_SAMPLER_HALTON, (const uint32_t *)ctx->haltonTables.p, bp.halton);
+    }
+    if (rp->sampler == KKD_SAMPLER_SOBOL) {
+        /* Integrator::configureSampler (librender/integrator.cpp:37-41): the crop size, blocked; arrays as kk/direct.cpp:44-47 request them */
+        sobolSetup(W, H, pathMode ? 0u : (nB > 1u ? 1u : 0u) + (nL > 1u ? 1u : 0u), nullptr, bp.sobol);
+        if (!ctx->sobolTables.p || ctx->sobolM != bp.sobol.m) {
+            std::vector<uint32_t> words;
+            if (!sobolTables(bp.sobol.m, words)) return fail(ctx, KKD_ERR_UNSUPPORTED, "sobol: no pixel look-up for this film resolution");
+            const int rcUp = upload(ctx, ctx->sobolTables, words.data(), words.size());
+            if (rcUp != KKD_OK) return rcUp;
+            KKD_HIP(ctx, hipStreamSynchronize(ctx->stream));      /* `words` is read by an asynchronous copy */
+            ctx->sobolM = bp.sobol.m;
+        }
+        bp.sobol.tables = (const uint32_t *)ctx->sobolTables.p;
     }
     bp.integrator = rp->integrator; bp.strictNormals = rp->strict_normals != 0;
     bp.maxDepth = rp->max_depth; bp.rrDepth = rp->rr_depth; bp.depth = 1;

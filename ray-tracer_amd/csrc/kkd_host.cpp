@@ -16,6 +16,7 @@
  *   reconstruction filter table            libcore/rfilter.cpp:37-55, rfilters/*.cpp
  */
 #include "kkd_host.h"
+#include "kkd_sobol_dirnums.h"
 #include <algorithm>
 #include <array>
 #include <cmath>
@@ -682,6 +683,82 @@ void haltonSetup(int resX, int resY, uint32_t nArrays, bool faure, const uint32_
     h.arrayEnd = 5u + 2u * nArrays;                                          /* halton.cpp:276-278 */
     h.tables = tables; h.faure = faure ? 1u : 0u; h.hammersley = 0; h.count = 0; h.factor = 0.f;
 }
+/* ---- sobol sampler tables (samplers/sobolseq.{h,cpp}) ---- */
+/* The 1024 x 52 generator matrices, top 32 bits of every 52-bit column, from Joe and Kuo's direction numbers: column k (1-based)
+ * of a dimension is m_k << (52 - k) with m_1 ... m_s given and m_k = 2 a_1 m_{k-1} ^ 4 a_2 m_{k-2} ^ ... ^ 2^s m_{k-s} ^ m_{k-s}
+ * beyond (the recurrence of the dimension's primitive polynomial x^s + a_1 x^(s-1) + ... + 1); dimension 0 is the identity
+ * (van der Corput).  Checked against the CRC-32 of the reference's table (kSobolMatrixCrc). */
+const std::vector<uint32_t> &sobolMatrices() {
+    static const std::vector<uint32_t> table = [] {
+        std::vector<uint32_t> t((size_t)kSobolDims * kSobolSize, 0u);
+        for (uint32_t k = 0; k < 32; ++k) t[k] = 1u << (31 - k);
+        const uint32_t *p = kJoeKuo;
+        for (uint32_t d = 1; d < kSobolDims; ++d) {
+            const uint32_t s = p[0], a = p[1];
+            uint64_t m[kSobolSize];
+            for (uint32_t k = 0; k < s; ++k) m[k] = p[2 + k];
+            p += 2 + s;
+            for (uint32_t k = s; k < kSobolSize; ++k) {
+                uint64_t x = m[k - s] ^ (m[k - s] << s);
+                for (uint32_t i = 1; i < s; ++i) if ((a >> (s - 1 - i)) & 1u) x ^= m[k - i] << i;
+                m[k] = x;
+            }
+            for (uint32_t k = 0; k < kSobolSize; ++k) t[(size_t)d * kSobolSize + k] = (uint32_t)((m[k] << (kSobolSize - 1 - k)) >> 20);
+        }
+        return t;
+    }();
+    return table;
+}
+
+uint32_t crc32Words(const uint32_t *w, size_t n) {      /* CRC-32 (IEEE 802.3, as zlib) of the words' little-endian bytes */
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; ++i)
+        for (int b = 0; b < 4; ++b) {
+            c ^= (w[i] >> (8 * b)) & 0xffu;
+            for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+        }
+    return ~c;
+}
+
+/* Tables of one render: the matrices, then for resolution 2^m the two 52-entry 64-bit tables sobolLookUp reads (kkd_math.h):
+ * [0] what index bit 2m + c contributes to T = (top m bits of coordinate 0) << m | (top m bits of coordinate 1), [1] the
+ * low index bits (below 2m) that make exactly bit j of T: the columns of the inverse, over GF(2), of the 2m x 2m matrix whose
+ * column i is the contribution of index bit i.  It is invertible because the first two dimensions form a (0, 2)-sequence:
+ * every 2^m x 2^m cell holds exactly one of any 2^(2m) consecutive points. */
+bool sobolTables(uint32_t m, std::vector<uint32_t> &words) {
+    const std::vector<uint32_t> &mat = sobolMatrices();
+    words.assign(mat.begin(), mat.end());
+    words.resize(mat.size() + 4 * kSobolSize, 0u);
+    if (m == 0 || 2 * m > 40) return m == 0;
+    auto contribution = [&](uint32_t bit) -> uint64_t {
+        if (bit >= kSobolSize) return 0;
+        return ((uint64_t)(mat[bit] >> (32 - m)) << m) | (uint64_t)(mat[kSobolSize + bit] >> (32 - m));
+    };
+    uint64_t *high = reinterpret_cast<uint64_t *>(words.data() + mat.size()), *inv = high + kSobolSize;
+    for (uint32_t c = 0; c < kSobolSize; ++c) high[c] = contribution(2 * m + c);
+    /* Gauss-Jordan on [A | I]: row i holds (column i of A, the combination of index bits that produces it) */
+    const uint32_t n = 2 * m;
+    std::vector<uint64_t> val(n), comb(n);
+    for (uint32_t i = 0; i < n; ++i) { val[i] = contribution(i); comb[i] = 1ull << i; }
+    for (uint32_t j = 0; j < n; ++j) {          /* make val[j] == 1 << j */
+        uint32_t piv = j;
+        while (piv < n && !((val[piv] >> j) & 1ull)) ++piv;
+        if (piv == n) return false;
+        std::swap(val[piv], val[j]); std::swap(comb[piv], comb[j]);
+        for (uint32_t i = 0; i < n; ++i) if (i != j && ((val[i] >> j) & 1ull)) { val[i] ^= val[j]; comb[i] ^= comb[j]; }
+    }
+    for (uint32_t j = 0; j < n; ++j) inv[j] = comb[j];
+    return true;
+}
+
+/* SobolSampler::setFilmResolution(res, blocked = true) + generate() (sobol.cpp:146-157, 173-179) */
+void sobolSetup(int resX, int resY, uint32_t nArrays, const uint32_t *tables, SobolSetup &s) {
+    uint32_t v = (uint32_t)std::max(1, std::max(resX, resY));                 /* math::roundToPowerOfTwo */
+    v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; v++;
+    s.m = 0; while ((1u << s.m) < v) ++s.m;
+    s.resolution = (float)v; s.arrayEnd = 5u + 2u * nArrays; s.pad = 0; s.tables = tables;
+}
+
 void hammersleySetup(int resX, int resY, uint32_t sampleCount, bool faure, const uint32_t *tables, HaltonSetup &h) {
     const int res[2] = { resX, resY };
     for (int i = 0; i < 2; ++i) {

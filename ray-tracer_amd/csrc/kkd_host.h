@@ -53,6 +53,14 @@ void haltonSetup(int resX, int resY, uint32_t nArrays, bool faure, const uint32_
 /* HammersleySampler::setFilmResolution(res, blocked = true) for a sampler of sampleCount samples (hammersley.cpp:181-197) */
 void hammersleySetup(int resX, int resY, uint32_t sampleCount, bool faure, const uint32_t *tables, HaltonSetup &h);
 
+/* sobol sampler: the 1024 x 52 generator matrices (32 bits per column) regenerated from Joe and Kuo's direction numbers; their CRC-32;
+ * the tables of one render (matrices + the pixel look-up of resolution 2^m: false if the look-up matrix is singular, which it never
+ * is); SobolSampler::setFilmResolution + the end of the dimensions reserved to nArrays 2D arrays (samplers/sobol.cpp:146-179) */
+const std::vector<uint32_t> &sobolMatrices();
+uint32_t crc32Words(const uint32_t *w, size_t n);
+bool sobolTables(uint32_t m, std::vector<uint32_t> &words);
+void sobolSetup(int resX, int resY, uint32_t nArrays, const uint32_t *tables, SobolSetup &s);
+
 uint16_t floatToHalf(float f);
 float halfToFloat(uint16_t h);
 

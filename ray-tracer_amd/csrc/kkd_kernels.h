@@ -25,7 +25,8 @@ struct BatchParams {
     uint32_t nB, nL, hideEmitters;
     uint32_t sampler, samplerDim, samplerSet;   /* KKD_SAMPLER_*; 'dimension'; size of the per-pixel point sets (ldsampler: a power of two, stratified: samplerRes^2) */
     uint32_t samplerRes;             /* stratified: cells per side (stratified.cpp:64-74) */
-    HaltonSetup halton;              /* KKD_SAMPLER_HALTON / _HALTON_PLAIN */
+    HaltonSetup halton;              /* KKD_SAMPLER_HALTON / _HALTON_PLAIN / _HAMMERSLEY* */
+    SobolSetup sobol;                /* KKD_SAMPLER_SOBOL */
     float diffScale;                 /* 1 / sqrt(spp): RayDifferential::scaleDifferential of the camera ray (integrator.cpp:144-145, 181) */
     uint32_t integrator, strictNormals;   /* KKD_INTEGRATOR_*; 'strictNormals' of the stock direct / path plugins */
     int32_t maxDepth, rrDepth;            /* path plugin: 'maxDepth', 'rrDepth' */

@@ -77,7 +77,13 @@ __device__ __forceinline__ bool isHalton(uint32_t mode) { return mode >= KKD_SAM
 __device__ __forceinline__ uint32_t haltonDim(const BatchParams &bp, uint32_t flat, uint32_t req2) {
     return haltonSkipArrays(bp.halton, bp.integrator == KKD_INTEGRATOR_PATH ? flat : req2);
 }
+/* sobol: the running dimension is counted as for halton; beyond the direction-number table (the reference stops with an error,
+ * sobol.cpp:235-237, 250-252) the independent stream takes over */
+__device__ __forceinline__ uint32_t sobolDim(const BatchParams &bp, uint32_t flat, uint32_t req2) {
+    return sobolSkipArrays(bp.sobol, bp.integrator == KKD_INTEGRATOR_PATH ? flat : req2);
+}
 __device__ __forceinline__ f2 draw2D(const BatchParams &bp, const SampleId &s, uint32_t flat, uint32_t req, uint32_t mode) {
+    if (mode == KKD_SAMPLER_SOBOL) { const uint32_t d = sobolDim(bp, flat, 2u * req); if (d + 1u < kSobolDimsMax) return sobolSample2D(bp.sobol, s.X, s.Y, s.sample, d); }
     if (mode == KKD_SAMPLER_LDSAMPLER && req < bp.samplerDim) return ldSample2D(bp.seed, s.pixel, 2u * req, s.sample, bp.samplerSet);
     if (isHalton(mode)) { const uint32_t d = haltonDim(bp, flat, 2u * req); if (d + 1u < kHaltonDims) return haltonSample2D(bp.halton, s.X, s.Y, s.sample, d); }
     const f2 u = sample2D(bp.seed, s.pixel, s.sample, flat);
@@ -87,6 +93,7 @@ __device__ __forceinline__ f2 draw2D(const BatchParams &bp, const SampleId &s, u
 __device__ __forceinline__ f2 draw2DArray(const BatchParams &bp, const SampleId &s, uint32_t flat, uint32_t array, uint32_t n, uint32_t e, uint32_t mode) {
     if (mode == KKD_SAMPLER_LDSAMPLER) return ldSample2D(bp.seed, s.pixel, 0x10000u + array, s.sample * n + e, bp.samplerSet * n);
     if (isHalton(mode)) return haltonArray2D(bp.halton, s.X, s.Y, array, (uint64_t)s.sample * n + e);
+    if (mode == KKD_SAMPLER_SOBOL) return sobolArray2D(bp.sobol, s.X, s.Y, array, (uint64_t)s.sample * n + e);
     const f2 u = sample2D(bp.seed, s.pixel, s.sample, flat);
     if (mode == KKD_SAMPLER_STRATIFIED) return latinHypercube2D(bp.seed, s.pixel, 0x10000u + array, s.sample * n + e, bp.samplerSet * n, u);
     return u;
@@ -94,6 +101,7 @@ __device__ __forceinline__ f2 draw2DArray(const BatchParams &bp, const SampleId 
 __device__ __forceinline__ float draw1D(const BatchParams &bp, const SampleId &s, uint32_t flat, uint32_t req, uint32_t mode) {
     if (mode == KKD_SAMPLER_LDSAMPLER && req < bp.samplerDim) return ldSample1D(bp.seed, s.pixel, 2u * req + 1u, s.sample, bp.samplerSet);
     if (isHalton(mode)) { const uint32_t d = haltonDim(bp, flat, flat); if (d < kHaltonDims) return haltonSample1D(bp.halton, s.X, s.Y, s.sample, d); }
+    if (mode == KKD_SAMPLER_SOBOL) { const uint32_t d = sobolDim(bp, flat, flat); if (d < kSobolDimsMax) return sobolSample1D(bp.sobol, s.X, s.Y, s.sample, d); }
     const float u = sample2D(bp.seed, s.pixel, s.sample, flat).x;
     if (mode == KKD_SAMPLER_STRATIFIED && req < bp.samplerDim) return stratSample1D(bp.seed, s.pixel, 2u * req + 1u, s.sample, bp.samplerRes, u);
     return u;
@@ -1006,6 +1014,7 @@ void launchShade(hipStream_t st, const DScene &sc, const BatchParams &bp, const 
     if (bp.sampler == KKD_SAMPLER_LDSAMPLER) hipLaunchKernelGGL(kShade<KKD_SAMPLER_LDSAMPLER>, grid, block, 0, st, sc, bp, wb);
     else if (bp.sampler == KKD_SAMPLER_STRATIFIED) hipLaunchKernelGGL(kShade<KKD_SAMPLER_STRATIFIED>, grid, block, 0, st, sc, bp, wb);
     else if (bp.sampler >= KKD_SAMPLER_HALTON && bp.sampler <= KKD_SAMPLER_HAMMERSLEY_PLAIN) hipLaunchKernelGGL(kShade<KKD_SAMPLER_HALTON>, grid, block, 0, st, sc, bp, wb);
+    else if (bp.sampler == KKD_SAMPLER_SOBOL) hipLaunchKernelGGL(kShade<KKD_SAMPLER_SOBOL>, grid, block, 0, st, sc, bp, wb);
     else hipLaunchKernelGGL(kShade<KKD_SAMPLER_INDEPENDENT>, grid, block, 0, st, sc, bp, wb);
     if (!bp.hideEmitters && sc.envEmitter >= 0) hipLaunchKernelGGL(kEnvMiss, dim3(blocksFor(bp.count, 256)), dim3(256), 0, st, sc, bp, wb);
 }

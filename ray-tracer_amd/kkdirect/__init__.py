@@ -511,6 +511,26 @@ class HammersleySampler(HaltonSampler):
         return dict(sampler=abi.SAMPLER_HAMMERSLEY if self.scramble == -1 else abi.SAMPLER_HAMMERSLEY_PLAIN)
 
 
+class SobolSampler:
+    """Host mirror of the 'sobol' plugin (reference src/samplers/sobol.cpp:82-107): sampleCount (any number), scramble = 0 (the
+    default; other values run through sampleTEA in the reference and are not offered)."""
+    PLUGIN_NAME = "sobol"
+
+    def __init__(self, props=None, **kw):
+        props = dict(props or {}, **kw)
+        self.sampleCount = int(props.pop("sampleCount", 4))
+        self.scramble = int(props.pop("scramble", 0))
+        if props:
+            raise ValueError("sobol: unreferenced properties %s" % sorted(props))
+        if self.sampleCount < 1:
+            raise ValueError("sobol: sampleCount must be positive")
+        if self.scramble != 0:
+            raise ValueError("sobol: only scramble = 0 is available")
+
+    def render_args(self):
+        return dict(sampler=abi.SAMPLER_SOBOL)
+
+
 class DirectIntegrator:
     """Host mirror of the reference's DirectIntegrator plugin (src/integrators/kk/direct.cpp:15-48).
 

@@ -96,6 +96,7 @@ class RenderParams(C.Structure):
 INTEGRATOR_KK, INTEGRATOR_DIRECT, INTEGRATOR_PATH = 0, 1, 2
 SAMPLER_INDEPENDENT, SAMPLER_LDSAMPLER, SAMPLER_STRATIFIED, SAMPLER_HALTON, SAMPLER_HALTON_PLAIN = 0, 1, 2, 3, 4
 SAMPLER_HAMMERSLEY, SAMPLER_HAMMERSLEY_PLAIN = 5, 6
+SAMPLER_SOBOL = 7
 MFILM_MATLAB, MFILM_MATHEMATICA = 0, 1
 
 
@@ -135,6 +136,8 @@ ENTRY_POINTS = {
     "kkd_probe_stratified": (C.c_int, [u64, u32, C.c_int, u32, u32, u32, u32, u32, pf32]),
     "kkd_probe_halton": (C.c_int, [u32, u32, C.c_int32, C.c_int32, C.c_int, C.c_int, u32, u32, u32, u32, pf32]),
     "kkd_probe_faure_permutation": (C.c_int, [u32, C.POINTER(C.c_uint16)]),
+    "kkd_probe_sobol": (C.c_int, [u32, u32, i32, i32, C.c_int, u32, u32, u32, u32, pf32]),
+    "kkd_probe_sobol_raw": (C.c_int, [u64, u32, u32, u32, u32, u32, C.POINTER(u32), C.POINTER(u64), C.POINTER(u32)]),
     "kkd_probe_rfilter": (C.c_int, [C.c_int, C.c_float, pf32, pf32, pf32, C.POINTER(C.c_int)]),
     "kkd_develop_device": (C.c_int, [C.c_void_p, C.c_void_p, u32, u32, i32, C.c_void_p]),
     "kkd_develop": (C.c_int, [C.c_void_p, pf32, u32, u32, i32, pf32]),
