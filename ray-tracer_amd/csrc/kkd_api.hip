@@ -86,12 +86,12 @@ struct kkd_ctx {
     DScene ds{};
     /* scene buffers */
     DevBuf nodes, wideNodes, tris, projTris, positions, normals, texcoords, indices, shapes, materials, emitters, emitterCdf, emitterGuide, areaGuide, areaCdf, rtTables,
-           envTexels, envCdfRows, envCdfCols, envRowWeights, envGuideRows, envGuideCols, envEwaLut;
+           envTexels, envCdfRows, envCdfCols, envRowWeights, envGuideRows, envGuideCols, envRecRows, envRecCols, envEwaLut;
     /* work buffers */
     DevBuf contRecs, contStacks, contCount, pathAlive, pBsdfRays, pBrec, pRefN, pShadowRays, pLrec, pSampleIdx;
     /* first-round step budgets of the round-based traversal; adapted from the share of rays the last batch parked */
     int capClosest = 26, capAny = 20;
-    DevBuf hits, accum, refN, bsdfRays, bsdfHits, brec0, shadowRays, occluded, lrec, film, counters, apiRays, apiHits;
+    DevBuf hits, accum, refN, bflags, bsdfRays, bsdfHits, brec0, shadowRays, occluded, lrec, film, counters, apiRays, apiHits;
     std::vector<hipEvent_t> events;
     std::vector<hipEvent_t> doneEvents;   /* one per batch in flight: recorded after the batch's splat (progress reports) */
     kkd_progress_fn progressFn = nullptr; void *progressUser = nullptr;
@@ -276,9 +276,9 @@ void kkd_destroy(kkd_ctx *ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     DevBuf *all[] = { &ctx->nodes, &ctx->wideNodes, &ctx->tris, &ctx->projTris, &ctx->positions, &ctx->normals, &ctx->texcoords, &ctx->indices, &ctx->shapes, &ctx->materials,
                       &ctx->emitters, &ctx->emitterCdf, &ctx->areaCdf, &ctx->rtTables, &ctx->envTexels, &ctx->envCdfRows, &ctx->envCdfCols,
-                      &ctx->envRowWeights, &ctx->contRecs, &ctx->contStacks, &ctx->contCount, &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->shadowRays,
+                      &ctx->envRowWeights, &ctx->contRecs, &ctx->contStacks, &ctx->contCount, &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bflags, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->shadowRays,
                       &ctx->occluded, &ctx->lrec, &ctx->film, &ctx->counters, &ctx->apiRays, &ctx->apiHits,
-                      &ctx->envGuideRows, &ctx->envGuideCols, &ctx->emitterGuide, &ctx->areaGuide, &ctx->pathAlive, &ctx->pBsdfRays, &ctx->pBrec, &ctx->pRefN, &ctx->pShadowRays, &ctx->pLrec, &ctx->pSampleIdx, &ctx->tileList, &ctx->envEwaLut, &ctx->haltonTables, &ctx->sobolTables };
+                      &ctx->envGuideRows, &ctx->envGuideCols, &ctx->envRecRows, &ctx->envRecCols, &ctx->emitterGuide, &ctx->areaGuide, &ctx->pathAlive, &ctx->pBsdfRays, &ctx->pBrec, &ctx->pRefN, &ctx->pShadowRays, &ctx->pLrec, &ctx->pSampleIdx, &ctx->tileList, &ctx->envEwaLut, &ctx->haltonTables, &ctx->sobolTables };
     for (DevBuf *b : all) b->release();
     for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->doneEvents) hipEventDestroy(ev);
@@ -339,6 +339,8 @@ static int uploadHostScene(kkd_ctx *ctx, const HostScene &hs, const kkd_scene_de
     UP(envRowWeights, hs.envRowWeights.data(), hs.envRowWeights.size())
     UP(envGuideRows, hs.envGuideRows.data(), hs.envGuideRows.size())
     UP(envGuideCols, hs.envGuideCols.data(), hs.envGuideCols.size())
+    UP(envRecRows, hs.envRecRows.data(), hs.envRecRows.size())
+    UP(envRecCols, hs.envRecCols.data(), hs.envRecCols.size())
     UP(envEwaLut, hs.envEwaLut.data(), hs.envEwaLut.size())
 #undef UP
     KKD_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -381,6 +383,7 @@ static int uploadHostScene(kkd_ctx *ctx, const HostScene &hs, const kkd_scene_de
     d.env.texels = (const uint32_t *)ctx->envTexels.p; d.env.cdfRows = (const float *)ctx->envCdfRows.p;
     d.env.cdfCols = (const float *)ctx->envCdfCols.p; d.env.rowWeights = (const float *)ctx->envRowWeights.p;
     d.env.guideRows = (const uint32_t *)ctx->envGuideRows.p; d.env.guideCols = (const uint32_t *)ctx->envGuideCols.p;
+    d.env.recRows = (const uint32_t *)ctx->envRecRows.p; d.env.recCols = (const uint32_t *)ctx->envRecCols.p;
     d.env.ewaLut = (const float *)ctx->envEwaLut.p;
     d.sensor = hs.sensor; d.filter = hs.filter;
     ctx->accelInfo = accel;
@@ -664,7 +667,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         if (e != hipSuccess) return fail(ctx, KKD_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
         auto need = [&](DevBuf &b, size_t bytes) { if (e == hipSuccess) e = b.ensure(bytes); };
         auto needL = [&](DevBuf &b, size_t bytes) { if (e == hipSuccess) e = b.ensure(((bytes + 255) / 256 * 256) * nLanes); };   /* one copy per lane */
-        needL(ctx->hits, S * sizeof(DHit)); needL(ctx->accum, S * 16); needL(ctx->refN, S * 16);
+        needL(ctx->hits, S * sizeof(DHit)); needL(ctx->accum, S * 16); needL(ctx->refN, pathMode ? S * 16 : 16); needL(ctx->bflags, pathMode ? 16 : S * nB);
         needL(ctx->bsdfRays, S * nB * sizeof(DRay)); needL(ctx->bsdfHits, S * nB * sizeof(DHit)); needL(ctx->brec0, S * nB * 16);
         /* continuation buffer of the two-launch traversal: half of the largest ray launch may be parked */
         contCap = std::min<uint64_t>(((uint64_t)S * std::max(nB, nL) / 2 / kContShards + 128) * kContShards, 0x7fffffffull);
@@ -688,7 +691,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         if (e != hipErrorOutOfMemory) return fail(ctx, KKD_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
         (void)hipGetLastError();
         /* give back what this attempt took (DevBuf::ensure frees before it grows, so the buffers that failed hold nothing) */
-        DevBuf *work[] = { &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->contRecs, &ctx->contStacks, &ctx->contCount,
+        DevBuf *work[] = { &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bflags, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->contRecs, &ctx->contStacks, &ctx->contCount,
                            &ctx->shadowRays, &ctx->occluded, &ctx->lrec, &ctx->pathAlive, &ctx->pBsdfRays, &ctx->pBrec, &ctx->pRefN, &ctx->pShadowRays, &ctx->pLrec, &ctx->pSampleIdx };
         for (DevBuf *b : work) b->release();
         if (getenv("KKD_VERBOSE")) fprintf(stderr, "kkd_render: out of device memory with %llu samples in flight on %d lane(s): backing off\n", (unsigned long long)batch, nLanes);
@@ -704,7 +707,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         cont.recs = (ContRec *)laneP(ctx->contRecs, contCap * sizeof(ContRec), l); cont.stacks = (uint4 *)laneP(ctx->contStacks, contCap * 16 * sizeof(uint32_t), l);
         cont.count = (uint32_t *)laneP(ctx->contCount, 4 * kContShards * 32 * sizeof(uint32_t), l);
         cont.perShard = (uint32_t)(contCap / kContShards); cont.iterCap = 0;
-        wb.hits = (DHit *)laneP(ctx->hits, S * sizeof(DHit), l); wb.accum = (float4 *)laneP(ctx->accum, S * 16, l); wb.refN = (float4 *)laneP(ctx->refN, S * 16, l);
+        wb.hits = (DHit *)laneP(ctx->hits, S * sizeof(DHit), l); wb.accum = (float4 *)laneP(ctx->accum, S * 16, l); wb.refN = (float4 *)laneP(ctx->refN, pathMode ? S * 16 : 16, l); wb.bflags = (uint8_t *)laneP(ctx->bflags, pathMode ? 16 : S * nB, l);
         wb.bsdfRays = (DRay *)laneP(ctx->bsdfRays, S * nB * sizeof(DRay), l); wb.bsdfHits = (DHit *)laneP(ctx->bsdfHits, S * nB * sizeof(DHit), l);
         wb.brec0 = (float4 *)laneP(ctx->brec0, S * nB * 16, l);
         wb.shadowRays = (DRay *)laneP(ctx->shadowRays, S * nL * sizeof(DRay), l); wb.occluded = (uint32_t *)laneP(ctx->occluded, S * nL * 4, l);
@@ -725,6 +728,8 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     bp.seed = ctx->cfg.seed; bp.stride = (uint32_t)S;
     bp.g = g; bp.gShift = gShift; bp.chunks = chunks; bp.spp = rp->spp; bp.sampleFirst = rp->sample_first;
     bp.nB = nB; bp.nL = nL; bp.hideEmitters = rp->hide_emitters != 0;
+    static const bool shadowFull = getenv("KKD_SHADOW_FULL") != nullptr;     /* developer switch (A/B runs): whole shadow rays */
+    bp.shadowShare = (!pathMode && nB > 0 && !shadowFull) ? 1u : 0u;
     /* Sampler::getSampleCount(): of the whole render when this call renders a share of every pixel's samples */
     const uint32_t sampleCountTotal = rp->sample_count_total ? rp->sample_count_total : rp->spp;
     bp.diffScale = 1.0f / std::sqrt((float)sampleCountTotal);
@@ -850,18 +855,24 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         launchShade(st, ctx->ds, bp, wb); launches[KKD_STAGE_SHADE]++;
         if (timeStages) hipEventRecord(ctx->events[ev++], st);
         /* all nB planes are contiguous when count == stride; otherwise trace plane by plane */
-        auto trace = [&](const DRay *rays, uint64_t n, bool any, void *out, int cls) {
+        auto trace = [&](const RaySource &rays, uint64_t n, bool any, void *out, int cls) {
             TraceContinuation c = cont; c.iterCap = any ? capAny : capClosest;
             c.count = cont.count + (any ? 2u : 0u) * kContShards * 32u;
             /* stage_launches counts kernel launches: a traversal in rounds is cont.rounds kernels */
             if (c.iterCap > 0) { launchTracePhased(st, ctx->ds, rays, n, any, count, out, ctr, cls, c); launches[any ? KKD_STAGE_SHADOW : KKD_STAGE_BSDF] += std::max(2, c.rounds) - 1; }
             else launchTrace(st, ctx->ds, rays, n, any, count, any ? 2 : 0, out, ctr, cls);
         };
-        if (bp.count == bp.stride) { trace(wb.bsdfRays, (uint64_t)S * nB, false, wb.bsdfHits, KKD_RAYS_BSDF); launches[KKD_STAGE_BSDF]++; }
-        else for (uint32_t b = 0; b < nB; ++b) { trace(wb.bsdfRays + (size_t)b * S, bp.count, false, wb.bsdfHits + (size_t)b * S, KKD_RAYS_BSDF); launches[KKD_STAGE_BSDF]++; }
+        auto whole = [](const DRay *rays) { return RaySource{ rays, nullptr, 0u }; };
+        /* shadow rays of plane l, from ray `first` of the plane on: whole rays, or directions beside the BSDF rays' origins */
+        auto shadowSrc = [&](uint32_t l) {
+            if (!bp.shadowShare) return whole(wb.shadowRays + (size_t)l * S);
+            return RaySource{ wb.bsdfRays, reinterpret_cast<const float4 *>(wb.shadowRays) + (size_t)l * S, (uint32_t)S };
+        };
+        if (bp.count == bp.stride) { trace(whole(wb.bsdfRays), (uint64_t)S * nB, false, wb.bsdfHits, KKD_RAYS_BSDF); launches[KKD_STAGE_BSDF]++; }
+        else for (uint32_t b = 0; b < nB; ++b) { trace(whole(wb.bsdfRays + (size_t)b * S), bp.count, false, wb.bsdfHits + (size_t)b * S, KKD_RAYS_BSDF); launches[KKD_STAGE_BSDF]++; }
         if (timeStages) hipEventRecord(ctx->events[ev++], st);
-        if (bp.count == bp.stride) { trace(wb.shadowRays, (uint64_t)S * nL, true, wb.occluded, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++; }
-        else for (uint32_t l = 0; l < nL; ++l) { trace(wb.shadowRays + (size_t)l * S, bp.count, true, (uint32_t *)wb.occluded + (size_t)l * S, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++; }
+        if (bp.count == bp.stride) { trace(shadowSrc(0), (uint64_t)S * nL, true, wb.occluded, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++; }
+        else for (uint32_t l = 0; l < nL; ++l) { trace(shadowSrc(l), bp.count, true, (uint32_t *)wb.occluded + (size_t)l * S, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++; }
         if (pathMode) {
             /* MIPathTracer: vertices at depth 2, 3, ... -- kPathBounce resolves the segments just traced and shades the next
              * vertices, then both ray kinds are traced again.  After every bounce the host reads back how many paths go on:
@@ -891,8 +902,8 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
                 identity = false;
                 if (alive == 0) { n = 0; break; }
                 compactNext = !noCompact && alive < (uint64_t)n * 3 / 4;
-                trace(sets[cur].bsdfRays, n, false, wb.bsdfHits, KKD_RAYS_BSDF); launches[KKD_STAGE_BSDF]++;
-                trace(sets[cur].shadowRays, n, true, wb.occluded, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++;
+                trace(whole(sets[cur].bsdfRays), n, false, wb.bsdfHits, KKD_RAYS_BSDF); launches[KKD_STAGE_BSDF]++;
+                trace(whole(sets[cur].shadowRays), n, true, wb.occluded, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++;
                 if (ctx->cancel.load()) break;
             }
             if (!everCompacted) {

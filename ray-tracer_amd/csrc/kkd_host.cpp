@@ -553,6 +553,28 @@ bool flattenScene(const kkd_scene_desc *sd, HostScene &hs, std::string &err, int
             guide(hs.envCdfRows.data(), (size_t)h + 1, kEnvGuideRows, hs.envGuideRows.data());
             hs.envGuideCols.resize((size_t)h * (kEnvGuideCols + 1));
             for (int y = 0; y < h; ++y) guide(hs.envCdfCols.data() + (size_t)y * (w + 1), (size_t)w + 1, kEnvGuideCols, hs.envGuideCols.data() + (size_t)y * (kEnvGuideCols + 1));
+            /* guide RECORDS (kkd_types.h, DEnvMap): per bucket the bracket and the CDF entries the search and the sample-reuse
+             * step read, cdf[first - 1 ... last + 1]; brackets that do not fit (low-probability stretches of a row, rarely
+             * sampled) keep the two-table path */
+            auto records = [](const float *cdf, const uint32_t *g, uint32_t G, uint32_t W, uint32_t *out) {
+                for (uint32_t b = 0; b < G; ++b, out += W) {
+                    const uint32_t first = g[b], n = g[b + 1] - g[b] + 1u;
+                    const bool fits = n + 3u <= W && first < (1u << 24);
+                    out[0] = fits ? (first | n << 24) : 0xFF000000u;
+                    for (uint32_t k = 0; k + 1u < W; ++k) {
+                        float v = 2.f;                      /* never below a sample: the device counts entries below it */
+                        if (fits && k <= n + 1u) v = first == 0u && k == 0u ? 0.f : cdf[first - 1u + k];
+                        std::memcpy(out + 1 + k, &v, 4);
+                    }
+                }
+            };
+            hs.envRecRows.assign((size_t)kEnvGuideRows * kEnvRecRowWords, 0u);
+            if (kEnvRecRowWords) records(hs.envCdfRows.data(), hs.envGuideRows.data(), kEnvGuideRows, kEnvRecRowWords, hs.envRecRows.data());
+            hs.envRecCols.assign((size_t)h * kEnvGuideCols * kEnvRecColWords, 0u);
+            if (kEnvRecColWords)
+                for (int y = 0; y < h; ++y)
+                    records(hs.envCdfCols.data() + (size_t)y * (w + 1), hs.envGuideCols.data() + (size_t)y * (kEnvGuideCols + 1), kEnvGuideCols,
+                            kEnvRecColWords, hs.envRecCols.data() + (size_t)y * kEnvGuideCols * kEnvRecColWords);
         }
         buildEnvPyramid(k.texels, w, h, hs);
         hs.env.normalization = 1.0f / (rowSum * (2 * kPi / w) * (kPi / h));

@@ -31,6 +31,7 @@ struct HostScene {
     std::vector<float> envEwaLut;
     std::vector<float> envCdfRows, envCdfCols, envRowWeights;
     std::vector<uint32_t> envGuideRows, envGuideCols;
+    std::vector<uint32_t> envRecRows, envRecCols;      /* 64-byte guide records (kkd_types.h) */
     DSensor sensor{};
     DFilter filter{};
     uint64_t nVerts = 0, nTris = 0;

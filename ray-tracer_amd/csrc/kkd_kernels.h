@@ -23,6 +23,7 @@ struct BatchParams {
      * group(w0) = (tile0 * bs^2 + pin0) * chunks + chunk0 */
     uint32_t chunk0, pin0, tile0, chunksShift /* log2(chunks) or 32 */, pixShift /* log2(bs^2) or 32 */;
     uint32_t nB, nL, hideEmitters;
+    uint32_t shadowShare;            /* shadow rays are stored as {direction, maxt} and start at the origin of the sample's first BSDF ray (RaySource) */
     uint32_t sampler, samplerDim, samplerSet;   /* KKD_SAMPLER_*; 'dimension'; size of the per-pixel point sets (ldsampler: a power of two, stratified: samplerRes^2) */
     uint32_t samplerRes;             /* stratified: cells per side (stratified.cpp:64-74) */
     HaltonSetup halton;              /* KKD_SAMPLER_HALTON / _HALTON_PLAIN / _HAMMERSLEY* */
@@ -45,20 +46,29 @@ struct BatchParams {
 struct WaveBuffers {
     DHit *hits;          /* primary hits                       [stride]      */
     float4 *accum;       /* Le / environment + alpha           [stride]      */
-    float4 *refN;        /* DirectSamplingRecord::refN; w = relative index of refraction along the path (path plugin) [stride] */
+    float4 *refN;        /* path plugin only: DirectSamplingRecord::refN; w = relative index of refraction along the path [stride] */
+    uint8_t *bflags;     /* direct plugins: all a BSDF sample needs of refN, 1 = dot(wo, refN) >= 0 (the test of Emitter::pdfDirect of the shape emitters) [nB * stride] */
     DRay *bsdfRays;      /*                                    [nB * stride] */
     DHit *bsdfHits;      /*                                    [nB * stride] */
     float4 *brec0;       /* bsdf weight rgb, +-pdf (<0: delta) [nB * stride] */
-    DRay *shadowRays;    /*                                    [nL * stride] */
+    DRay *shadowRays;    /* BatchParams::shadowShare: float4 {direction, maxt} instead [nL * stride] */
     uint32_t *occluded;  /*                                    [nL * stride] */
     float4 *lrec;        /* MIS-weighted light contribution    [nL * stride] */
     uint32_t *sampleIdx; /* path plugin: sample (index into accum) of the path in this slot [stride] */
 };
 
+/* Where a traversal launch reads its rays.  dirs == nullptr: ray k = rays[k].  Otherwise ray k takes direction and maxt
+ * from dirs[k] and origin and mint from rays[k mod stride]: the shadow rays of a sample start where its first BSDF ray
+ * starts (the shading point), so kShade stores that point once (16 bytes less written per shadow ray). */
+struct RaySource { const DRay *rays; const float4 *dirs; uint32_t stride; };
+
 void launchPrimary(hipStream_t st, bool count, const DScene &sc, const BatchParams &bp, DHit *hits, DeviceCounters *ctr);
 /* outMode: 0 = DHit with LeafTri slot, 1 = DHit with global primitive id, 2 = uint32 occlusion flags (anyHit only) */
 /* rayClass: which DeviceCounters slot the launch accounts to */
-void launchTrace(hipStream_t st, const DScene &sc, const DRay *rays, uint64_t n, bool anyHit, bool count, int outMode, void *out, DeviceCounters *ctr, int rayClass);
+void launchTrace(hipStream_t st, const DScene &sc, const RaySource &rays, uint64_t n, bool anyHit, bool count, int outMode, void *out, DeviceCounters *ctr, int rayClass);
+inline void launchTrace(hipStream_t st, const DScene &sc, const DRay *rays, uint64_t n, bool anyHit, bool count, int outMode, void *out, DeviceCounters *ctr, int rayClass) {
+    launchTrace(st, sc, RaySource{ rays, nullptr, 0u }, n, anyHit, count, outMode, out, ctr, rayClass);
+}
 /* A ray parked by kTraceRound after its iteration budget: everything Walk needs to go on (32 bytes + 16 stack words; the best
  * hit's distance is tmax). */
 struct alignas(16) ContRec { uint32_t ray, cur, sp; float tmax; uint32_t pend; float u, v; uint32_t id; };
@@ -70,7 +80,7 @@ struct TraceContinuation { ContRec *recs; uint4 *stacks; uint32_t *count; uint32
 /* Two-launch variant of launchTrace for the render path (outMode 0 or 2): waves stop after cont.iterCap steps, the few lanes
  * still walking are parked in cont and finished by a second, densely packed launch.  cont.count must be zero on entry
  * (the launcher clears the counters). */
-void launchTracePhased(hipStream_t st, const DScene &sc, const DRay *rays, uint64_t n, bool anyHit, bool count, void *out, DeviceCounters *ctr,
+void launchTracePhased(hipStream_t st, const DScene &sc, const RaySource &rays, uint64_t n, bool anyHit, bool count, void *out, DeviceCounters *ctr,
                        int rayClass, const TraceContinuation &cont);
 void launchShade(hipStream_t st, const DScene &sc, const BatchParams &bp, const WaveBuffers &wb);
 /* path plugin: resolve the segment traced last, play Russian roulette, shade the vertex at bp.depth; alive: kAliveShards counters of paths that go on */

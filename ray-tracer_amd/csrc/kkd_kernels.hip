@@ -162,15 +162,25 @@ __global__ void __launch_bounds__(BLOCK, !PACKET || KKD_PRIMARY_RAYS == 1 ? 8 : 
 
 template <int OUT> __device__ __forceinline__ void storeTraceResult(void *__restrict__ out, uint64_t i, DHit h, const LeafTri *__restrict__ tris);
 
+/* SHARE: RaySource with dirs (kkd_kernels.h) */
+template <bool SHARE>
+__device__ __forceinline__ DRay loadRay(const DRay *__restrict__ rays, const float4 *__restrict__ dirs, uint32_t stride, uint64_t k) {
+    if (!SHARE) return rays[k];
+    const uint32_t k32 = (uint32_t)k, oi = k32 < stride ? k32 : k32 % stride;
+    const float4 o = reinterpret_cast<const float4 *>(rays)[2 * (size_t)oi], d = dirs[k];
+    DRay r; r.ox = o.x; r.oy = o.y; r.oz = o.z; r.mint = o.w; r.dx = d.x; r.dy = d.y; r.dz = d.z; r.maxt = d.w;
+    return r;
+}
+
 /* ---- generic ray-buffer traversal ------------------------------------------------------------------ */
 /* OUT: 0 = DHit with LeafTri slot (internal), 1 = DHit with global primitive id (C ABI), 2 = occlusion word */
-template <bool ANY, bool COUNT, int OUT, bool PROJ, int STACK, int BLOCK>
+template <bool ANY, bool COUNT, int OUT, bool PROJ, int STACK, int BLOCK, bool SHARE = false>
 __global__ void __launch_bounds__(BLOCK, 8) kTrace(const Node4 *__restrict__ nodes, const LeafTri *__restrict__ tris, const ProjTri *__restrict__ projTris,
-                                                const DRay *__restrict__ rays, uint64_t n, void *__restrict__ out, DeviceCounters *ctr, int cls) {
+                                                const DRay *__restrict__ rays, const float4 *__restrict__ dirs, uint32_t stride, uint64_t n, void *__restrict__ out, DeviceCounters *ctr, int cls) {
     __shared__ uint32_t sstack[STACK * BLOCK];
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     DRay ray; ray.maxt = -1.f; ray.mint = 0.f; ray.ox = ray.oy = ray.oz = 0.f; ray.dx = ray.dy = 0.f; ray.dz = 1.f;
-    if (i < n) ray = rays[i];
+    if (i < n) ray = loadRay<SHARE>(rays, dirs, stride, i);
     uint32_t nn = 0, nt = 0;
     DHit h = traverse<ANY, COUNT, PROJ, STACK, BLOCK>(nodes, PROJ ? (const void *)projTris : (const void *)tris, ray, sstack, nn, nt);
     if (i < n) storeTraceResult<OUT>(out, i, h, tris);
@@ -203,9 +213,9 @@ static_assert(kStackLds == 16, "TraceContinuation stores 16 stack words per park
 
 /* One round.  FIRST: lanes take rays [0, n) of the ray buffer; else lanes take the records parked in `in` by the round
  * before.  next.iterCap > 0: stop after that many steps and park what is still walking in `next`; else walk to the end. */
-template <bool ANY, bool COUNT, int OUT, bool PROJ, bool FIRST, int STACK, int BLOCK>
+template <bool ANY, bool COUNT, int OUT, bool PROJ, bool FIRST, int STACK, int BLOCK, bool SHARE = false>
 __global__ void __launch_bounds__(BLOCK, 8) kTraceRound(const Node4 *__restrict__ nodes, const LeafTri *__restrict__ tris, const ProjTri *__restrict__ projTris,
-                                                        const DRay *__restrict__ rays, uint64_t n, void *__restrict__ out, DeviceCounters *ctr, int cls,
+                                                        const DRay *__restrict__ rays, const float4 *__restrict__ dirs, uint32_t stride, uint64_t n, void *__restrict__ out, DeviceCounters *ctr, int cls,
                                                         TraceContinuation in, TraceContinuation next) {
     __shared__ uint32_t sstack[STACK * BLOCK];
     DRay ray; ray.maxt = -1.f; ray.mint = 0.f; ray.ox = ray.oy = ray.oz = 0.f; ray.dx = ray.dy = 0.f; ray.dz = 1.f;
@@ -215,7 +225,7 @@ __global__ void __launch_bounds__(BLOCK, 8) kTraceRound(const Node4 *__restrict_
     if (FIRST && !ANY) {
         const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
         mine = i < n;
-        if (mine) { ray = rays[i]; r.ray = (uint32_t)i; }
+        if (mine) { ray = loadRay<SHARE>(rays, dirs, stride, i); r.ray = (uint32_t)i; }
     } else if (FIRST) {
         /* Shadow rays: a quarter of them is dead on C2 (shading queued nothing for the sample: maxt < mint).  Dead rays get
          * their miss right here, and when that empties at least one wave the live rays of the block are packed into its
@@ -225,7 +235,7 @@ __global__ void __launch_bounds__(BLOCK, 8) kTraceRound(const Node4 *__restrict_
         const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
         DRay own = ray;
         const bool have = i < n;
-        if (have) own = rays[i];
+        if (have) own = loadRay<SHARE>(rays, dirs, stride, i);
         const bool live = have && own.maxt > adaptiveMinT<ANY>(own.mint, own.ox, own.oy, own.oz);   /* what Walk::begin tests */
         if (have && !live) { DHit miss; miss.t = kInf; miss.u = 0.f; miss.v = 0.f; miss.id = kNoHit; storeTraceResult<OUT>(out, i, miss, tris); }
         uint32_t *perm = sstack, *wcount = sstack + BLOCK;
@@ -248,7 +258,7 @@ __global__ void __launch_bounds__(BLOCK, 8) kTraceRound(const Node4 *__restrict_
             if (mine) {
                 const uint32_t src = perm[threadIdx.x];
                 r.ray = (uint32_t)((uint64_t)blockIdx.x * BLOCK + src);
-                ray = rays[r.ray];
+                ray = loadRay<SHARE>(rays, dirs, stride, r.ray);
             }
         }
     } else {
@@ -259,7 +269,7 @@ __global__ void __launch_bounds__(BLOCK, 8) kTraceRound(const Node4 *__restrict_
         const uint32_t e = chunk * BLOCK + threadIdx.x;
         mine = e < nParked;
         inSlot = (size_t)shard * in.perShard + e;
-        if (mine) { r = in.recs[inSlot]; ray = rays[r.ray]; }
+        if (mine) { r = in.recs[inSlot]; ray = loadRay<SHARE>(rays, dirs, stride, r.ray); }
     }
     uint32_t nn = 0, nt = 0;
     const void *triTable = PROJ ? (const void *)projTris : (const void *)tris;
@@ -335,9 +345,9 @@ __global__ void __launch_bounds__(BLOCK, 8) kTraceRound(const Node4 *__restrict_
 #ifndef KKD_TAIL_CHUNK
 #define KKD_TAIL_CHUNK 8
 #endif
-template <bool ANY, bool COUNT, int OUT, bool PROJ, int STACK, int BLOCK>
+template <bool ANY, bool COUNT, int OUT, bool PROJ, int STACK, int BLOCK, bool SHARE = false>
 __global__ void __launch_bounds__(BLOCK, 8) kTraceTail(const Node4 *__restrict__ nodes, const LeafTri *__restrict__ tris, const ProjTri *__restrict__ projTris,
-                                                       const DRay *__restrict__ rays, void *__restrict__ out, DeviceCounters *ctr, int cls, TraceContinuation in) {
+                                                       const DRay *__restrict__ rays, const float4 *__restrict__ dirs, uint32_t stride, void *__restrict__ out, DeviceCounters *ctr, int cls, TraceContinuation in) {
     __shared__ uint32_t sstack[STACK * BLOCK];
     const uint32_t shard = blockIdx.x % kContShards;
     const uint32_t nParked = min(in.count[shard * 32u], in.perShard);
@@ -364,7 +374,7 @@ __global__ void __launch_bounds__(BLOCK, 8) kTraceTail(const Node4 *__restrict__
                 if (e < nParked) {
                     const size_t slot = (size_t)shard * in.perShard + e;
                     const ContRec r = in.recs[slot];
-                    ray = rays[r.ray]; myRay = r.ray; have = true;
+                    ray = loadRay<SHARE>(rays, dirs, stride, r.ray); myRay = r.ray; have = true;
                     w.begin(ray);
                     w.resume(r.cur, r.pend, (int)r.sp, r.tmax, r.u, r.v, r.id, r.id != kNoHit ? tris[r.id].prim : 0u);
 #pragma unroll
@@ -408,6 +418,12 @@ __device__ __forceinline__ void storeRay(DRay *dst, const DRay &r) {
     p[0] = make_float4(r.ox, r.oy, r.oz, r.mint); p[1] = make_float4(r.dx, r.dy, r.dz, r.maxt);
 }
 
+/* kShade's shadow rays: whole, or (BatchParams::shadowShare) direction and maxt only -- the origin is the first BSDF ray's */
+__device__ __forceinline__ void storeShadowRay(const WaveBuffers &wb, const BatchParams &bp, size_t slot, const DRay &r) {
+    if (bp.shadowShare) reinterpret_cast<float4 *>(wb.shadowRays)[slot] = make_float4(r.dx, r.dy, r.dz, r.maxt);
+    else storeRay(wb.shadowRays + slot, r);
+}
+
 #ifndef KKD_SHADE_WAVES
 #define KKD_SHADE_WAVES 4      /* blocks of 256 per CU = waves per SIMD */
 #endif
@@ -436,7 +452,7 @@ __global__ void __launch_bounds__(KKD_SHADE_BLOCK, KKD_SHADE_WAVES * 256 / KKD_S
     if (!shade) {
         DRay dead; killRay(dead);
         for (uint32_t b = 0; b < nB; ++b) { storeRay(wb.bsdfRays + (size_t)b * bp.stride + i, dead); wb.brec0[(size_t)b * bp.stride + i] = make_float4(0.f, 0.f, 0.f, 0.f); }
-        for (uint32_t l = 0; l < nL; ++l) { storeRay(wb.shadowRays + (size_t)l * bp.stride + i, dead); wb.lrec[(size_t)l * bp.stride + i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        for (uint32_t l = 0; l < nL; ++l) { storeShadowRay(wb, bp, (size_t)l * bp.stride + i, dead); wb.lrec[(size_t)l * bp.stride + i] = make_float4(0.f, 0.f, 0.f, 0.f); }
         wb.accum[i] = accum;
         return;
     }
@@ -470,6 +486,7 @@ __global__ void __launch_bounds__(KKD_SHADE_BLOCK, KKD_SHADE_WAVES * 256 / KKD_S
         woLocal = f3(0.f); bsdfPdf = 0.f; sampledType = 0u;
         const f3 bsdfVal = ablation(bp, 8u) ? f3(0.f) : sampleBsdf(sc, its.material, its.wi, u, woLocal, bsdfPdf, sampledType);   /* ($KKD_DEBUG bit 8, ablation build: no BSDF sampling) */
         DRay r; killRay(r);
+        if (bp.shadowShare && b == 0u) { r.ox = its.p.x; r.oy = its.p.y; r.oz = its.p.z; r.mint = kEpsilon; }   /* the shadow rays start here too (RaySource); maxt < 0: still no ray */
         float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!isZero(bsdfVal) && !dead) {
             const f3 wo = its.sh.toWorld(woLocal);
@@ -482,8 +499,10 @@ __global__ void __launch_bounds__(KKD_SHADE_BLOCK, KKD_SHADE_WAVES * 256 / KKD_S
         }
         storeRay(wb.bsdfRays + (size_t)b * bp.stride + i, r);
         wb.brec0[(size_t)b * bp.stride + i] = rec;
+        /* kResolve needs refN only for the sign test of the emitters' pdfDirect on this ray: one byte instead of the normal */
+        if (bp.integrator != KKD_INTEGRATOR_PATH) wb.bflags[(size_t)b * bp.stride + i] = dot(f3(r.dx, r.dy, r.dz), refN) >= 0.f ? 1u : 0u;
     }
-    wb.refN[i] = make_float4(refN.x, refN.y, refN.z, pathEta);
+    if (bp.integrator == KKD_INTEGRATOR_PATH) wb.refN[i] = make_float4(refN.x, refN.y, refN.z, pathEta);
 
     /* integrateLight :127-160 -- everything but the visibility test, already MIS-weighted (:172-177) */
     for (uint32_t l = 0; l < nL; ++l) {
@@ -514,7 +533,7 @@ __global__ void __launch_bounds__(KKD_SHADE_BLOCK, KKD_SHADE_WAVES * 256 / KKD_S
                 }
             }
         }
-        storeRay(wb.shadowRays + (size_t)l * bp.stride + i, r);
+        storeShadowRay(wb, bp, (size_t)l * bp.stride + i, r);
         wb.lrec[(size_t)l * bp.stride + i] = rec;
     }
     wb.accum[i] = accum;
@@ -770,9 +789,11 @@ __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveB
             if (h.id != kNoHit && (h.id & kHitNotEmitter)) continue;   /* hit a surface that does not emit: Le = 0 */
             if (h.id == kNoHit && sc.envEmitter < 0) continue;
             const DRay r = wb.bsdfRays[(size_t)b * bp.stride + i];
-            const float4 rn = wb.refN[i];
             const f3 rd(r.dx, r.dy, r.dz);
-            DirectRec dRec; dRec.ref = f3(r.ox, r.oy, r.oz); dRec.refN = f3(rn.x, rn.y, rn.z);
+            DirectRec dRec; dRec.ref = f3(r.ox, r.oy, r.oz);
+            /* pdfDirect only asks for the sign of dot(d, refN): the direct plugins carry that bit (kShade), the path plugin the normal */
+            if (bp.integrator == KKD_INTEGRATOR_PATH) { const float4 rn = wb.refN[i]; dRec.refN = f3(rn.x, rn.y, rn.z); }
+            else dRec.refN = wb.bflags[(size_t)b * bp.stride + i] ? rd : -rd;
             f3 value;
             if (h.id != kNoHit) {
                 Its bIts; fillIntersection<false>(sc, rd, h, bIts);
@@ -795,8 +816,9 @@ __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveB
             L += value * f3(rec.x, rec.y, rec.z) * (weight * invNB);
         }
         for (uint32_t l = 0; l < nL; ++l) {
+            if (wb.occluded[(size_t)l * bp.stride + i] != 0u) continue;     /* (the record of an occluded sample is not read) */
             const float4 rec = wb.lrec[(size_t)l * bp.stride + i];
-            if (wb.occluded[(size_t)l * bp.stride + i] == 0u) { L.x += rec.x; L.y += rec.y; L.z += rec.z; }
+            L.x += rec.x; L.y += rec.y; L.z += rec.z;
         }
         /* ImageBlock::put rejects samples with negative or non-finite components */
         const bool ok = isfinite(L.x) && isfinite(L.y) && isfinite(L.z) && L.x >= 0.f && L.y >= 0.f && L.z >= 0.f;
@@ -946,12 +968,15 @@ void launchPrimary(hipStream_t st, bool count, const DScene &sc, const BatchPara
 }
 
 template <bool ANY, bool COUNT, int OUT>
-static void launchTraceT(hipStream_t st, const DScene &sc, const DRay *rays, uint64_t n, void *out, DeviceCounters *ctr, int cls) {
-    if (sc.projTris) hipLaunchKernelGGL((kTrace<ANY, COUNT, OUT, true, kStackLds, 256>), dim3(blocksFor(n, 256)), dim3(256), 0, st, sc.nodes, sc.tris, sc.projTris, rays, n, out, ctr, cls);
-    else hipLaunchKernelGGL((kTrace<ANY, COUNT, OUT, false, kStackLds, 256>), dim3(blocksFor(n, 256)), dim3(256), 0, st, sc.nodes, sc.tris, sc.projTris, rays, n, out, ctr, cls);
+static void launchTraceT(hipStream_t st, const DScene &sc, const RaySource &rays, uint64_t n, void *out, DeviceCounters *ctr, int cls) {
+    constexpr bool canShare = ANY && OUT == 2;       /* only the render path's shadow rays come without origins */
+#define KKD_LT(P, S) hipLaunchKernelGGL((kTrace<ANY, COUNT, OUT, P, kStackLds, 256, S>), dim3(blocksFor(n, 256)), dim3(256), 0, st, sc.nodes, sc.tris, sc.projTris, rays.rays, rays.dirs, rays.stride, n, out, ctr, cls)
+    if (canShare && rays.dirs) { if (sc.projTris) KKD_LT(true, canShare); else KKD_LT(false, canShare); }
+    else { if (sc.projTris) KKD_LT(true, false); else KKD_LT(false, false); }
+#undef KKD_LT
 }
 
-void launchTrace(hipStream_t st, const DScene &sc, const DRay *rays, uint64_t n, bool anyHit, bool count, int outMode, void *out, DeviceCounters *ctr, int cls) {
+void launchTrace(hipStream_t st, const DScene &sc, const RaySource &rays, uint64_t n, bool anyHit, bool count, int outMode, void *out, DeviceCounters *ctr, int cls) {
     if (n == 0) return;
     if (anyHit) {
         if (outMode == 2) { if (count) launchTraceT<true, true, 2>(st, sc, rays, n, out, ctr, cls); else launchTraceT<true, false, 2>(st, sc, rays, n, out, ctr, cls); }
@@ -962,8 +987,8 @@ void launchTrace(hipStream_t st, const DScene &sc, const DRay *rays, uint64_t n,
     }
 }
 
-template <bool ANY, bool COUNT, int OUT, bool PROJ>
-static void launchPhasedT(hipStream_t st, const DScene &sc, const DRay *rays, uint64_t n, void *out, DeviceCounters *ctr, int cls, const TraceContinuation &cont) {
+template <bool ANY, bool COUNT, int OUT, bool PROJ, bool SHARE = false>
+static void launchPhasedT(hipStream_t st, const DScene &sc, const RaySource &rays, uint64_t n, void *out, DeviceCounters *ctr, int cls, const TraceContinuation &cont) {
     /* rounds: [0, cap) on all rays, then (rounds > 2 only) cap more steps on what is left, ...; the last round walks to the end
      * as persistent waves that draw the parked rays themselves (kTraceTail).  With more than two rounds the two halves of the
      * continuation buffer alternate as input and output; with two the first round parks into the whole buffer. */
@@ -984,22 +1009,25 @@ static void launchPhasedT(hipStream_t st, const DScene &sc, const DRay *rays, ui
         TraceContinuation in = bufs[(r + 1) & 1], next = bufs[r & 1];
         next.iterCap = (r + 1 < rounds) ? (r == 0 ? cont.iterCap : cont.iterCapLater) : 0;
         if (r >= 2 && next.iterCap > 0) hipMemsetAsync(next.count, 0, kContShards * 32 * sizeof(uint32_t), st);
-        if (r == 0) hipLaunchKernelGGL((kTraceRound<ANY, COUNT, OUT, PROJ, true, kStackLds, 256>), dim3(blocksFor(n, 256)), block, 0, st,
-                                       sc.nodes, sc.tris, sc.projTris, rays, n, out, ctr, cls, in, next);
+        if (r == 0) hipLaunchKernelGGL((kTraceRound<ANY, COUNT, OUT, PROJ, true, kStackLds, 256, SHARE>), dim3(blocksFor(n, 256)), block, 0, st,
+                                       sc.nodes, sc.tris, sc.projTris, rays.rays, rays.dirs, rays.stride, n, out, ctr, cls, in, next);
         else if (next.iterCap == 0 && tailBlocks > 0)
-            hipLaunchKernelGGL((kTraceTail<ANY, COUNT, OUT, PROJ, kStackLds, 256>), dim3(kContShards * (uint32_t)std::min(tailBlocks, 8)), block, 0, st,
-                               sc.nodes, sc.tris, sc.projTris, rays, out, ctr, cls, in);
-        else hipLaunchKernelGGL((kTraceRound<ANY, COUNT, OUT, PROJ, false, kStackLds, 256>), resumeGrid, block, 0, st,
-                                sc.nodes, sc.tris, sc.projTris, rays, n, out, ctr, cls, in, next);
+            hipLaunchKernelGGL((kTraceTail<ANY, COUNT, OUT, PROJ, kStackLds, 256, SHARE>), dim3(kContShards * (uint32_t)std::min(tailBlocks, 8)), block, 0, st,
+                               sc.nodes, sc.tris, sc.projTris, rays.rays, rays.dirs, rays.stride, out, ctr, cls, in);
+        else hipLaunchKernelGGL((kTraceRound<ANY, COUNT, OUT, PROJ, false, kStackLds, 256, SHARE>), resumeGrid, block, 0, st,
+                                sc.nodes, sc.tris, sc.projTris, rays.rays, rays.dirs, rays.stride, n, out, ctr, cls, in, next);
     }
 }
 
-void launchTracePhased(hipStream_t st, const DScene &sc, const DRay *rays, uint64_t n, bool anyHit, bool count, void *out, DeviceCounters *ctr,
+void launchTracePhased(hipStream_t st, const DScene &sc, const RaySource &rays, uint64_t n, bool anyHit, bool count, void *out, DeviceCounters *ctr,
                        int cls, const TraceContinuation &cont) {
     if (n == 0) return;
     const bool proj = sc.projTris != nullptr;
 #define KKD_PH(A, C, O, P) launchPhasedT<A, C, O, P>(st, sc, rays, n, out, ctr, cls, cont)
-    if (anyHit) {
+    if (anyHit && rays.dirs) {
+        if (count) { if (proj) launchPhasedT<true, true, 2, true, true>(st, sc, rays, n, out, ctr, cls, cont); else launchPhasedT<true, true, 2, false, true>(st, sc, rays, n, out, ctr, cls, cont); }
+        else { if (proj) launchPhasedT<true, false, 2, true, true>(st, sc, rays, n, out, ctr, cls, cont); else launchPhasedT<true, false, 2, false, true>(st, sc, rays, n, out, ctr, cls, cont); }
+    } else if (anyHit) {
         if (count) { if (proj) KKD_PH(true, true, 2, true); else KKD_PH(true, true, 2, false); }
         else { if (proj) KKD_PH(true, false, 2, true); else KKD_PH(true, false, 2, false); }
     } else {

@@ -130,6 +130,34 @@ __device__ __forceinline__ uint32_t envSampleReuse(const float *cdf, uint32_t si
     return index;
 }
 
+/* the same through the bucket's guide record of W words (kkd_types.h), loaded whole: the CDF does not decrease, so the index
+ * std::lower_bound returns is the bracket's start plus the number of entries below the sample, counted in registers */
+template <uint32_t W>
+__device__ __forceinline__ uint32_t envSampleReuseRec(const float *cdf, uint32_t size, float &sample, const uint32_t *guide, const uint32_t *recs, uint32_t G) {
+    static_assert(W % 4 == 0 && W >= 4, "records are read as 16-byte words");
+    const uint32_t b = min((uint32_t)(sample * (float)G), G - 1u);
+    uint32_t w[W];
+#pragma unroll
+    for (uint32_t q = 0; q < W / 4; ++q) {
+        const uint4 v = reinterpret_cast<const uint4 *>(recs + (size_t)b * W)[q];
+        w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+    }
+    if ((w[0] >> 24) == 0xFFu) return envSampleReuse(cdf, size, sample, guide, G);
+    const uint32_t first = w[0] & 0xFFFFFFu;
+    uint32_t lo = 0;                                                /* w[2 + i] = cdf[first + i]; 2.0f past the bracket */
+#pragma unroll
+    for (uint32_t i = 2; i < W; ++i) lo += __uint_as_float(w[i]) < sample ? 1u : 0u;
+    const uint32_t abs = first + lo;                                /* what std::lower_bound returns */
+    const uint32_t index = min(abs > 0 ? abs - 1 : 0u, size - 1);
+    const uint32_t sel = index + 2u - first;                        /* w[sel] = cdf[index]; index >= first - 1 */
+    float c0 = __uint_as_float(w[1]), c1 = __uint_as_float(w[2]);
+#pragma unroll
+    for (uint32_t j = 2; j + 1 < W; ++j)
+        if (sel == j) { c0 = __uint_as_float(w[j]); c1 = __uint_as_float(w[j + 1]); }
+    sample = fdiv(sample - c0, c1 - c0);
+    return index;
+}
+
 __device__ __forceinline__ f3 rot3(const float *R, f3 v) {
     return f3(R[0] * v.x + R[1] * v.y + R[2] * v.z, R[3] * v.x + R[4] * v.y + R[5] * v.z, R[6] * v.x + R[7] * v.y + R[8] * v.z);
 }
@@ -278,8 +306,17 @@ __device__ __forceinline__ float envPdfDirection(const DEnvMap &e, f3 d) {
 }
 /* envmap.cpp:567-600 */
 __device__ __forceinline__ void envSampleDirection(const DEnvMap &e, f2 sample, f3 &d, f3 &value, float &pdf) {
+#if KKD_ENV_REC_ROWS == 0
     const uint32_t row = envSampleReuse(e.cdfRows, (uint32_t)e.h, sample.y, e.guideRows, kEnvGuideRows);
+#else
+    const uint32_t row = envSampleReuseRec<kEnvRecRowWords>(e.cdfRows, (uint32_t)e.h, sample.y, e.guideRows, e.recRows, kEnvGuideRows);
+#endif
+#if KKD_ENV_REC_COLS == 0
     const uint32_t col = envSampleReuse(e.cdfCols + (size_t)row * (e.w + 1), (uint32_t)e.w, sample.x, e.guideCols + row * (kEnvGuideCols + 1u), kEnvGuideCols);
+#else
+    const uint32_t col = envSampleReuseRec<kEnvRecColWords>(e.cdfCols + (size_t)row * (e.w + 1), (uint32_t)e.w, sample.x, e.guideCols + row * (kEnvGuideCols + 1u),
+                                                            e.recCols + (size_t)row * kEnvGuideCols * kEnvRecColWords, kEnvGuideCols);
+#endif
     const float px = (float)col + intervalToTent(sample.x), py = (float)row + intervalToTent(sample.y);
     f3 a, b; int yPos;
     envBilinearRows(e, px, py, a, b, yPos);

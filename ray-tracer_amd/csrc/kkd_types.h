@@ -123,6 +123,12 @@ struct DEnvMap {
      * in [guide[b], guide[b + 1]] and the binary search starts on that bracket (same result, 3-6 dependent loads, not 11-12) */
     const uint32_t *guideRows; /* kEnvGuideRows + 1                                          */
     const uint32_t *guideCols; /* h * (kEnvGuideCols + 1)                                    */
+    /* guide records: per bucket one 32-byte record holding the bracket of the bucket and every CDF
+     * entry the search and the sample-reuse step touch, so a CDF lookup is ONE load into registers
+     * instead of a guide load, the loads of the search and the two of the reuse step, each waiting on the one before; brackets that do not fit use the two tables above.  Same
+     * index as std::lower_bound either way (envmap.cpp:653-658).  Null unless built with -DKKD_ENV_RECORDS (see below: measured, not kept). */
+    const uint32_t *recRows;   /* kEnvGuideRows * kEnvRecRowWords                            */
+    const uint32_t *recCols;   /* h * kEnvGuideCols * kEnvRecColWords                        */
     /* MIP pyramid of the filtered lookup for camera rays (envmap.cpp:394-407): level l starts at texel levelOfs[l] of
      * texels and is max(1, ceil(w / 2^l)) x max(1, ceil(h / 2^l)) texels; levelOfs[0] = 0 */
     int32_t nLevels; uint32_t levelOfs[kEnvMaxLevels]; uint16_t levelW[kEnvMaxLevels], levelH[kEnvMaxLevels];
@@ -132,6 +138,24 @@ static constexpr uint32_t kEmitterGuide = 1024, kAreaGuide = 256, kAreaGuideMinP
 /* (powers of two: sample * G is exact.  Every step of a CDF search is a dependent load in kShade, which runs at 4 waves per
  * SIMD: 256 / 64 buckets gave C4's shade stage 380 ms per step, 1024 / 256: 364, 4096 / 1024: 357; 4 KB per envmap row) */
 static constexpr uint32_t kEnvGuideRows = 4096, kEnvGuideCols = 1024;
+/* guide records (DEnvMap::recRows/recCols), an experiment of round 3 that is NOT built by default (-DKKD_ENV_RECORDS builds it):
+ * word 0 = first | n << 24 (n = 0xFF: no record, use the two tables), then cdf[first - 1 ... last + 1] and 2.0f up to the
+ * end: brackets of up to W - 3 entries.  Measured on C4 (profiles/r3_ab_env_records.txt): the shade stage takes 371 ms per
+ * frame with 32-byte records read whole into registers, 380 ms with 64-byte ones, 390 ms with 64-byte ones searched in
+ * memory -- against 357 ms for the two small tables, which stay in the vector cache and L2 while 67-134 MB of records do
+ * not, and whose dependent loads kShade hides behind its other work. */
+#ifdef KKD_ENV_RECORDS
+#ifndef KKD_ENV_REC_ROWS
+#define KKD_ENV_REC_ROWS 8
+#endif
+#ifndef KKD_ENV_REC_COLS
+#define KKD_ENV_REC_COLS 8
+#endif
+#else
+#define KKD_ENV_REC_ROWS 0
+#define KKD_ENV_REC_COLS 0
+#endif
+static constexpr uint32_t kEnvRecRowWords = KKD_ENV_REC_ROWS, kEnvRecColWords = KKD_ENV_REC_COLS;
 
 struct DSensor {
     float toWorld[12];         /* rows of the affine camera-to-world matrix                   */
