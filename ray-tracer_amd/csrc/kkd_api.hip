@@ -91,7 +91,7 @@ struct kkd_ctx {
     DevBuf contRecs, contStacks, contCount, pathAlive, pBsdfRays, pBrec, pRefN, pShadowRays, pLrec, pSampleIdx;
     /* first-round step budgets of the round-based traversal; adapted from the share of rays the last batch parked */
     int capClosest = 26, capAny = 20;
-    DevBuf hits, accum, refN, bflags, bsdfRays, bsdfHits, brec0, shadowRays, occluded, lrec, film, counters, apiRays, apiHits;
+    DevBuf hits, accum, refN, bflags, aflags, bsdfRays, bsdfHits, brec0, shadowRays, occluded, lrec, film, counters, apiRays, apiHits;
     std::vector<hipEvent_t> events;
     std::vector<hipEvent_t> doneEvents;   /* one per batch in flight: recorded after the batch's splat (progress reports) */
     kkd_progress_fn progressFn = nullptr; void *progressUser = nullptr;
@@ -276,7 +276,7 @@ void kkd_destroy(kkd_ctx *ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     DevBuf *all[] = { &ctx->nodes, &ctx->wideNodes, &ctx->tris, &ctx->projTris, &ctx->positions, &ctx->normals, &ctx->texcoords, &ctx->indices, &ctx->shapes, &ctx->materials,
                       &ctx->emitters, &ctx->emitterCdf, &ctx->areaCdf, &ctx->rtTables, &ctx->envTexels, &ctx->envCdfRows, &ctx->envCdfCols,
-                      &ctx->envRowWeights, &ctx->contRecs, &ctx->contStacks, &ctx->contCount, &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bflags, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->shadowRays,
+                      &ctx->envRowWeights, &ctx->contRecs, &ctx->contStacks, &ctx->contCount, &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bflags, &ctx->aflags, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->shadowRays,
                       &ctx->occluded, &ctx->lrec, &ctx->film, &ctx->counters, &ctx->apiRays, &ctx->apiHits,
                       &ctx->envGuideRows, &ctx->envGuideCols, &ctx->envRecRows, &ctx->envRecCols, &ctx->emitterGuide, &ctx->areaGuide, &ctx->pathAlive, &ctx->pBsdfRays, &ctx->pBrec, &ctx->pRefN, &ctx->pShadowRays, &ctx->pLrec, &ctx->pSampleIdx, &ctx->tileList, &ctx->envEwaLut, &ctx->haltonTables, &ctx->sobolTables };
     for (DevBuf *b : all) b->release();
@@ -667,7 +667,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         if (e != hipSuccess) return fail(ctx, KKD_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
         auto need = [&](DevBuf &b, size_t bytes) { if (e == hipSuccess) e = b.ensure(bytes); };
         auto needL = [&](DevBuf &b, size_t bytes) { if (e == hipSuccess) e = b.ensure(((bytes + 255) / 256 * 256) * nLanes); };   /* one copy per lane */
-        needL(ctx->hits, S * sizeof(DHit)); needL(ctx->accum, S * 16); needL(ctx->refN, pathMode ? S * 16 : 16); needL(ctx->bflags, pathMode ? 16 : S * nB);
+        needL(ctx->hits, S * sizeof(DHit)); needL(ctx->accum, S * 16); needL(ctx->refN, pathMode ? S * 16 : 16); needL(ctx->bflags, pathMode ? 16 : S * nB); needL(ctx->aflags, pathMode ? 16 : S);
         needL(ctx->bsdfRays, S * nB * sizeof(DRay)); needL(ctx->bsdfHits, S * nB * sizeof(DHit)); needL(ctx->brec0, S * nB * 16);
         /* continuation buffer of the two-launch traversal: half of the largest ray launch may be parked */
         contCap = std::min<uint64_t>(((uint64_t)S * std::max(nB, nL) / 2 / kContShards + 128) * kContShards, 0x7fffffffull);
@@ -691,7 +691,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         if (e != hipErrorOutOfMemory) return fail(ctx, KKD_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
         (void)hipGetLastError();
         /* give back what this attempt took (DevBuf::ensure frees before it grows, so the buffers that failed hold nothing) */
-        DevBuf *work[] = { &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bflags, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->contRecs, &ctx->contStacks, &ctx->contCount,
+        DevBuf *work[] = { &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bflags, &ctx->aflags, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->contRecs, &ctx->contStacks, &ctx->contCount,
                            &ctx->shadowRays, &ctx->occluded, &ctx->lrec, &ctx->pathAlive, &ctx->pBsdfRays, &ctx->pBrec, &ctx->pRefN, &ctx->pShadowRays, &ctx->pLrec, &ctx->pSampleIdx };
         for (DevBuf *b : work) b->release();
         if (getenv("KKD_VERBOSE")) fprintf(stderr, "kkd_render: out of device memory with %llu samples in flight on %d lane(s): backing off\n", (unsigned long long)batch, nLanes);
@@ -707,7 +707,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         cont.recs = (ContRec *)laneP(ctx->contRecs, contCap * sizeof(ContRec), l); cont.stacks = (uint4 *)laneP(ctx->contStacks, contCap * 16 * sizeof(uint32_t), l);
         cont.count = (uint32_t *)laneP(ctx->contCount, 4 * kContShards * 32 * sizeof(uint32_t), l);
         cont.perShard = (uint32_t)(contCap / kContShards); cont.iterCap = 0;
-        wb.hits = (DHit *)laneP(ctx->hits, S * sizeof(DHit), l); wb.accum = (float4 *)laneP(ctx->accum, S * 16, l); wb.refN = (float4 *)laneP(ctx->refN, pathMode ? S * 16 : 16, l); wb.bflags = (uint8_t *)laneP(ctx->bflags, pathMode ? 16 : S * nB, l);
+        wb.hits = (DHit *)laneP(ctx->hits, S * sizeof(DHit), l); wb.accum = (float4 *)laneP(ctx->accum, S * 16, l); wb.refN = (float4 *)laneP(ctx->refN, pathMode ? S * 16 : 16, l); wb.bflags = (uint8_t *)laneP(ctx->bflags, pathMode ? 16 : S * nB, l); wb.aflags = (uint8_t *)laneP(ctx->aflags, pathMode ? 16 : S, l);
         wb.bsdfRays = (DRay *)laneP(ctx->bsdfRays, S * nB * sizeof(DRay), l); wb.bsdfHits = (DHit *)laneP(ctx->bsdfHits, S * nB * sizeof(DHit), l);
         wb.brec0 = (float4 *)laneP(ctx->brec0, S * nB * 16, l);
         wb.shadowRays = (DRay *)laneP(ctx->shadowRays, S * nL * sizeof(DRay), l); wb.occluded = (uint32_t *)laneP(ctx->occluded, S * nL * 4, l);

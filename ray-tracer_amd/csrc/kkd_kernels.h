@@ -46,6 +46,7 @@ struct BatchParams {
 struct WaveBuffers {
     DHit *hits;          /* primary hits                       [stride]      */
     float4 *accum;       /* Le / environment + alpha           [stride]      */
+    uint8_t *aflags;     /* direct plugins: 1 = accum[i] is stored; 0 = it is (0, 0, 0, 1), the camera ray hit a surface that does not emit, and was not written [stride] */
     float4 *refN;        /* path plugin only: DirectSamplingRecord::refN; w = relative index of refraction along the path [stride] */
     uint8_t *bflags;     /* direct plugins: all a BSDF sample needs of refN, 1 = dot(wo, refN) >= 0 (the test of Emitter::pdfDirect of the shape emitters) [nB * stride] */
     DRay *bsdfRays;      /*                                    [nB * stride] */

@@ -453,12 +453,15 @@ __global__ void __launch_bounds__(KKD_SHADE_BLOCK, KKD_SHADE_WAVES * 256 / KKD_S
         DRay dead; killRay(dead);
         for (uint32_t b = 0; b < nB; ++b) { storeRay(wb.bsdfRays + (size_t)b * bp.stride + i, dead); wb.brec0[(size_t)b * bp.stride + i] = make_float4(0.f, 0.f, 0.f, 0.f); }
         for (uint32_t l = 0; l < nL; ++l) { storeShadowRay(wb, bp, (size_t)l * bp.stride + i, dead); wb.lrec[(size_t)l * bp.stride + i] = make_float4(0.f, 0.f, 0.f, 0.f); }
-        wb.accum[i] = accum;
+        /* a camera ray that left the scene: kEnvMiss adds the environment to what is stored here */
+        if (bp.integrator == KKD_INTEGRATOR_PATH || s.active) wb.accum[i] = accum;
+        if (bp.integrator != KKD_INTEGRATOR_PATH) wb.aflags[i] = s.active ? 1u : 0u;
         return;
     }
     const f3 rd(ray.dx, ray.dy, ray.dz);
     fillIntersection<true>(sc, rd, hit, its);
-    if (its.emitter >= 0 && !bp.hideEmitters) {                      /* :66-67 */
+    const bool seesEmitter = its.emitter >= 0 && !bp.hideEmitters;
+    if (seesEmitter) {                                               /* :66-67 */
         const f3 le = areaEval(sc.emitters[its.emitter], its.sh.n, -rd);
         accum.x += le.x; accum.y += le.y; accum.z += le.z;
     }
@@ -536,7 +539,9 @@ __global__ void __launch_bounds__(KKD_SHADE_BLOCK, KKD_SHADE_WAVES * 256 / KKD_S
         storeShadowRay(wb, bp, (size_t)l * bp.stride + i, r);
         wb.lrec[(size_t)l * bp.stride + i] = rec;
     }
-    wb.accum[i] = accum;
+    /* most camera rays hit a surface that does not emit: their (0, 0, 0, 1) is a flag byte, not 16 bytes written here and read by kResolve */
+    if (bp.integrator == KKD_INTEGRATOR_PATH || seesEmitter) wb.accum[i] = accum;
+    if (bp.integrator != KKD_INTEGRATOR_PATH) wb.aflags[i] = seesEmitter ? 1u : 0u;
 }
 
 /* ---- K4b: next vertex of the path plugin (MIPathTracer::Li, integrators/path/path.cpp:135-287) -------------------------------
@@ -778,7 +783,7 @@ __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveB
     if (s.active) {
         const f2 jit = draw2D(bp, s, 0u, 0u, INDEP ? KKD_SAMPLER_INDEPENDENT : bp.sampler);
         sx = (float)s.X + jit.x; sy = (float)s.Y + jit.y;
-        const float4 acc = wb.accum[i];
+        const float4 acc = (bp.integrator == KKD_INTEGRATOR_PATH || wb.aflags[i]) ? wb.accum[i] : make_float4(0.f, 0.f, 0.f, 1.f);
         f3 L(acc.x, acc.y, acc.z);
         const float cB = fdiv((float)nB, (float)(nB + nL)), cL = fdiv((float)nL, (float)(nB + nL));
         const float invNB = frcp((float)nB);
