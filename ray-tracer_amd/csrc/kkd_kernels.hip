@@ -162,6 +162,28 @@ __global__ void __launch_bounds__(BLOCK, !PACKET || KKD_PRIMARY_RAYS == 1 ? 8 : 
 
 template <int OUT> __device__ __forceinline__ void storeTraceResult(void *__restrict__ out, uint64_t i, DHit h, const LeafTri *__restrict__ tris);
 
+#ifndef KKD_SORT_OCTANT
+#define KKD_SORT_OCTANT 8      /* bins of the first round's direction sort: 8 = octants (kept), 64 = octahedral cells, 0 = none */
+#endif
+#ifndef KKD_SORT_ANY
+#define KKD_SORT_ANY 1         /* the same for shadow rays (0: only their dead rays are squeezed out, the layout of round 2) */
+#endif
+#if KKD_SORT_OCTANT
+/* direction -> one of 64 bins: the octahedral map of the unit sphere cut into 8 x 8 cells, numbered along a Morton curve so
+ * that neighbouring bins hold neighbouring directions */
+__device__ __forceinline__ uint32_t directionBin(float dx, float dy, float dz) {
+#if KKD_SORT_OCTANT == 8
+    return (dx < 0.f ? 1u : 0u) | (dy < 0.f ? 2u : 0u) | (dz < 0.f ? 4u : 0u);
+#else
+    const float inv = frcp(fabsf(dx) + fabsf(dy) + fabsf(dz));
+    float u = dx * inv, v = dy * inv;
+    if (dz < 0.f) { const float fu = (1.f - fabsf(v)) * (u < 0.f ? -1.f : 1.f), fv = (1.f - fabsf(u)) * (v < 0.f ? -1.f : 1.f); u = fu; v = fv; }
+    const uint32_t ix = min((uint32_t)max((u + 1.f) * 4.f, 0.f), 7u), iy = min((uint32_t)max((v + 1.f) * 4.f, 0.f), 7u);
+    return (ix & 1u) | (iy & 1u) << 1 | (ix & 2u) << 1 | (iy & 2u) << 2 | (ix & 4u) << 2 | (iy & 4u) << 3;
+#endif
+}
+#endif
+
 /* SHARE: RaySource with dirs (kkd_kernels.h) */
 template <bool SHARE>
 __device__ __forceinline__ DRay loadRay(const DRay *__restrict__ rays, const float4 *__restrict__ dirs, uint32_t stride, uint64_t k) {
@@ -222,11 +244,50 @@ __global__ void __launch_bounds__(BLOCK, 8) kTraceRound(const Node4 *__restrict_
     ContRec r; r.ray = 0; r.cur = kTraversalDone; r.sp = 0; r.tmax = -1.f; r.pend = 0u; r.u = r.v = 0.f; r.id = kNoHit;
     bool mine;                      /* this lane holds a ray */
     size_t inSlot = 0;
+#if KKD_SORT_OCTANT
+    /* The block's live rays sorted by the octant of their direction (counting sort in LDS, ray -> lane only: results go to the ray's own slot), so that the lanes of a
+     * wave walk the tree in the same order; dead rays get their miss here */
+    if (FIRST && (!ANY || KKD_SORT_ANY)) {
+        const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+        DRay own = ray;
+        const bool have = i < n;
+        if (have) own = loadRay<SHARE>(rays, dirs, stride, i);
+        const bool live = have && own.maxt > adaptiveMinT<ANY>(own.mint, own.ox, own.oy, own.oz);
+        if (have && !live) { DHit miss; miss.t = kInf; miss.u = 0.f; miss.v = 0.f; miss.id = kNoHit; storeTraceResult<OUT>(out, i, miss, tris); }
+        uint32_t *perm = sstack, *cnt = sstack + BLOCK;
+        if (threadIdx.x <= 64u) cnt[threadIdx.x] = 0u;
+        __syncthreads();
+        const uint32_t key = directionBin(own.dx, own.dy, own.dz);
+        uint32_t pos = 0;
+        if (live) pos = atomicAdd(&cnt[key], 1u);
+        __syncthreads();
+        if (threadIdx.x < 64u) {                                /* first wave: exclusive prefix sums of the 64 counters */
+            const uint32_t c = cnt[threadIdx.x];
+            uint32_t incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d); if ((int)threadIdx.x >= d) incl += o; }
+            cnt[threadIdx.x] = incl - c;
+            if (threadIdx.x == 63u) cnt[64] = incl;
+        }
+        __syncthreads();
+        const uint32_t base = cnt[key], total = cnt[64];
+        if (live) perm[base + pos] = threadIdx.x;
+        __syncthreads();
+        if (total == 0u) return;                                /* block-uniform */
+        mine = threadIdx.x < total;
+        if (mine) {
+            const uint32_t src = perm[threadIdx.x];
+            r.ray = (uint32_t)((uint64_t)blockIdx.x * BLOCK + src);
+            ray = loadRay<SHARE>(rays, dirs, stride, r.ray);
+        }
+    } else if (FIRST) {
+#else
     if (FIRST && !ANY) {
         const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
         mine = i < n;
         if (mine) { ray = loadRay<SHARE>(rays, dirs, stride, i); r.ray = (uint32_t)i; }
     } else if (FIRST) {
+#endif
         /* Shadow rays: a quarter of them is dead on C2 (shading queued nothing for the sample: maxt < mint).  Dead rays get
          * their miss right here, and when that empties at least one wave the live rays of the block are packed into its
          * first waves: a wave full of holes runs as long as a full one, an empty wave leaves at once (C2 shadow stage 37.5
