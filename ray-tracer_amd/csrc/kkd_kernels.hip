@@ -165,6 +165,9 @@ template <int OUT> __device__ __forceinline__ void storeTraceResult(void *__rest
 #ifndef KKD_SORT_OCTANT
 #define KKD_SORT_OCTANT 8      /* bins of the first round's direction sort: 8 = octants (kept), 64 = octahedral cells, 0 = none */
 #endif
+#ifndef KKD_FIRST_BLOCK
+#define KKD_FIRST_BLOCK 256    /* workgroup of the first traversal round: the rays that are sorted together */
+#endif
 #ifndef KKD_SORT_ANY
 #define KKD_SORT_ANY 1         /* the same for shadow rays (0: only their dead rays are squeezed out, the layout of round 2) */
 #endif
@@ -1075,7 +1078,7 @@ static void launchPhasedT(hipStream_t st, const DScene &sc, const RaySource &ray
         TraceContinuation in = bufs[(r + 1) & 1], next = bufs[r & 1];
         next.iterCap = (r + 1 < rounds) ? (r == 0 ? cont.iterCap : cont.iterCapLater) : 0;
         if (r >= 2 && next.iterCap > 0) hipMemsetAsync(next.count, 0, kContShards * 32 * sizeof(uint32_t), st);
-        if (r == 0) hipLaunchKernelGGL((kTraceRound<ANY, COUNT, OUT, PROJ, true, kStackLds, 256, SHARE>), dim3(blocksFor(n, 256)), block, 0, st,
+        if (r == 0) hipLaunchKernelGGL((kTraceRound<ANY, COUNT, OUT, PROJ, true, kStackLds, KKD_FIRST_BLOCK, SHARE>), dim3(blocksFor(n, KKD_FIRST_BLOCK)), dim3(KKD_FIRST_BLOCK), 0, st,
                                        sc.nodes, sc.tris, sc.projTris, rays.rays, rays.dirs, rays.stride, n, out, ctr, cls, in, next);
         else if (next.iterCap == 0 && tailBlocks > 0)
             hipLaunchKernelGGL((kTraceTail<ANY, COUNT, OUT, PROJ, kStackLds, 256, SHARE>), dim3(kContShards * (uint32_t)std::min(tailBlocks, 8)), block, 0, st,
