@@ -121,7 +121,7 @@ def test_render_params_are_validated(gpu):
     sc = _cornell(16, 16)
     with gpu.Context(device=0, seed=1).upload(sc) as ctx:
         with pytest.raises(Exception, match="unknown sampler"):
-            ctx.render(4, sampler=7)
+            ctx.render(4, sampler=kkdirect.abi.SAMPLER_SOBOL + 1)
         with pytest.raises(Exception, match="sample_count_total"):
             ctx.render(8, sample_first=12, sample_count_total=16)
         film, _ = kkdirect.DirectIntegrator().render(sc, ctx=ctx, sampler=kkdirect.LowDiscrepancySampler(sampleCount=8))
