@@ -91,7 +91,7 @@ struct kkd_ctx {
     DevBuf contRecs, contStacks, contCount, pathAlive, pBsdfRays, pBrec, pRefN, pShadowRays, pLrec, pSampleIdx;
     /* first-round step budgets of the round-based traversal; adapted from the share of rays the last batch parked */
     int capClosest = 26, capAny = 20;
-    DevBuf hits, accum, refN, bflags, aflags, bsdfRays, bsdfHits, brec0, shadowRays, occluded, lrec, film, counters, apiRays, apiHits;
+    DevBuf hits, accum, refN, bflags, aflags, origins, bsdfRays, bsdfHits, brec0, shadowRays, occluded, lrec, film, counters, apiRays, apiHits;
     std::vector<hipEvent_t> events;
     std::vector<hipEvent_t> doneEvents;   /* one per batch in flight: recorded after the batch's splat (progress reports) */
     kkd_progress_fn progressFn = nullptr; void *progressUser = nullptr;
@@ -276,7 +276,7 @@ void kkd_destroy(kkd_ctx *ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     DevBuf *all[] = { &ctx->nodes, &ctx->wideNodes, &ctx->tris, &ctx->projTris, &ctx->positions, &ctx->normals, &ctx->texcoords, &ctx->indices, &ctx->shapes, &ctx->materials,
                       &ctx->emitters, &ctx->emitterCdf, &ctx->areaCdf, &ctx->rtTables, &ctx->envTexels, &ctx->envCdfRows, &ctx->envCdfCols,
-                      &ctx->envRowWeights, &ctx->contRecs, &ctx->contStacks, &ctx->contCount, &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bflags, &ctx->aflags, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->shadowRays,
+                      &ctx->envRowWeights, &ctx->contRecs, &ctx->contStacks, &ctx->contCount, &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bflags, &ctx->aflags, &ctx->origins, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->shadowRays,
                       &ctx->occluded, &ctx->lrec, &ctx->film, &ctx->counters, &ctx->apiRays, &ctx->apiHits,
                       &ctx->envGuideRows, &ctx->envGuideCols, &ctx->envRecRows, &ctx->envRecCols, &ctx->emitterGuide, &ctx->areaGuide, &ctx->pathAlive, &ctx->pBsdfRays, &ctx->pBrec, &ctx->pRefN, &ctx->pShadowRays, &ctx->pLrec, &ctx->pSampleIdx, &ctx->tileList, &ctx->envEwaLut, &ctx->haltonTables, &ctx->sobolTables };
     for (DevBuf *b : all) b->release();
@@ -667,7 +667,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         if (e != hipSuccess) return fail(ctx, KKD_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
         auto need = [&](DevBuf &b, size_t bytes) { if (e == hipSuccess) e = b.ensure(bytes); };
         auto needL = [&](DevBuf &b, size_t bytes) { if (e == hipSuccess) e = b.ensure(((bytes + 255) / 256 * 256) * nLanes); };   /* one copy per lane */
-        needL(ctx->hits, S * sizeof(DHit)); needL(ctx->accum, S * 16); needL(ctx->refN, pathMode ? S * 16 : 16); needL(ctx->bflags, pathMode ? 16 : S * nB); needL(ctx->aflags, pathMode ? 16 : S);
+        needL(ctx->hits, S * sizeof(DHit)); needL(ctx->accum, S * 16); needL(ctx->refN, pathMode ? S * 16 : 16); needL(ctx->bflags, pathMode ? 16 : S * nB); needL(ctx->aflags, pathMode ? 16 : S); needL(ctx->origins, pathMode ? 16 : S * 16);
         needL(ctx->bsdfRays, S * nB * sizeof(DRay)); needL(ctx->bsdfHits, S * nB * sizeof(DHit)); needL(ctx->brec0, S * nB * 16);
         /* continuation buffer of the two-launch traversal: half of the largest ray launch may be parked */
         contCap = std::min<uint64_t>(((uint64_t)S * std::max(nB, nL) / 2 / kContShards + 128) * kContShards, 0x7fffffffull);
@@ -691,7 +691,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         if (e != hipErrorOutOfMemory) return fail(ctx, KKD_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
         (void)hipGetLastError();
         /* give back what this attempt took (DevBuf::ensure frees before it grows, so the buffers that failed hold nothing) */
-        DevBuf *work[] = { &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bflags, &ctx->aflags, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->contRecs, &ctx->contStacks, &ctx->contCount,
+        DevBuf *work[] = { &ctx->hits, &ctx->accum, &ctx->refN, &ctx->bflags, &ctx->aflags, &ctx->origins, &ctx->bsdfRays, &ctx->bsdfHits, &ctx->brec0, &ctx->contRecs, &ctx->contStacks, &ctx->contCount,
                            &ctx->shadowRays, &ctx->occluded, &ctx->lrec, &ctx->pathAlive, &ctx->pBsdfRays, &ctx->pBrec, &ctx->pRefN, &ctx->pShadowRays, &ctx->pLrec, &ctx->pSampleIdx };
         for (DevBuf *b : work) b->release();
         if (getenv("KKD_VERBOSE")) fprintf(stderr, "kkd_render: out of device memory with %llu samples in flight on %d lane(s): backing off\n", (unsigned long long)batch, nLanes);
@@ -707,7 +707,7 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
         cont.recs = (ContRec *)laneP(ctx->contRecs, contCap * sizeof(ContRec), l); cont.stacks = (uint4 *)laneP(ctx->contStacks, contCap * 16 * sizeof(uint32_t), l);
         cont.count = (uint32_t *)laneP(ctx->contCount, 4 * kContShards * 32 * sizeof(uint32_t), l);
         cont.perShard = (uint32_t)(contCap / kContShards); cont.iterCap = 0;
-        wb.hits = (DHit *)laneP(ctx->hits, S * sizeof(DHit), l); wb.accum = (float4 *)laneP(ctx->accum, S * 16, l); wb.refN = (float4 *)laneP(ctx->refN, pathMode ? S * 16 : 16, l); wb.bflags = (uint8_t *)laneP(ctx->bflags, pathMode ? 16 : S * nB, l); wb.aflags = (uint8_t *)laneP(ctx->aflags, pathMode ? 16 : S, l);
+        wb.hits = (DHit *)laneP(ctx->hits, S * sizeof(DHit), l); wb.accum = (float4 *)laneP(ctx->accum, S * 16, l); wb.refN = (float4 *)laneP(ctx->refN, pathMode ? S * 16 : 16, l); wb.bflags = (uint8_t *)laneP(ctx->bflags, pathMode ? 16 : S * nB, l); wb.aflags = (uint8_t *)laneP(ctx->aflags, pathMode ? 16 : S, l); wb.origins = (float4 *)laneP(ctx->origins, pathMode ? 16 : S * 16, l);
         wb.bsdfRays = (DRay *)laneP(ctx->bsdfRays, S * nB * sizeof(DRay), l); wb.bsdfHits = (DHit *)laneP(ctx->bsdfHits, S * nB * sizeof(DHit), l);
         wb.brec0 = (float4 *)laneP(ctx->brec0, S * nB * 16, l);
         wb.shadowRays = (DRay *)laneP(ctx->shadowRays, S * nL * sizeof(DRay), l); wb.occluded = (uint32_t *)laneP(ctx->occluded, S * nL * 4, l);
@@ -728,8 +728,8 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     bp.seed = ctx->cfg.seed; bp.stride = (uint32_t)S;
     bp.g = g; bp.gShift = gShift; bp.chunks = chunks; bp.spp = rp->spp; bp.sampleFirst = rp->sample_first;
     bp.nB = nB; bp.nL = nL; bp.hideEmitters = rp->hide_emitters != 0;
-    static const bool shadowFull = getenv("KKD_SHADOW_FULL") != nullptr;     /* developer switch (A/B runs): whole shadow rays */
-    bp.shadowShare = (!pathMode && nB > 0 && !shadowFull) ? 1u : 0u;
+    static const bool wholeRays = getenv("KKD_RAYS_WHOLE") != nullptr;     /* developer switch (A/B runs): 32-byte rays, the layout of round 2 */
+    bp.splitRays = (!pathMode && !wholeRays) ? 1u : 0u;
     /* Sampler::getSampleCount(): of the whole render when this call renders a share of every pixel's samples */
     const uint32_t sampleCountTotal = rp->sample_count_total ? rp->sample_count_total : rp->spp;
     bp.diffScale = 1.0f / std::sqrt((float)sampleCountTotal);
@@ -863,13 +863,14 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
             else launchTrace(st, ctx->ds, rays, n, any, count, any ? 2 : 0, out, ctr, cls);
         };
         auto whole = [](const DRay *rays) { return RaySource{ rays, nullptr, 0u }; };
-        /* shadow rays of plane l, from ray `first` of the plane on: whole rays, or directions beside the BSDF rays' origins */
-        auto shadowSrc = [&](uint32_t l) {
-            if (!bp.shadowShare) return whole(wb.shadowRays + (size_t)l * S);
-            return RaySource{ wb.bsdfRays, reinterpret_cast<const float4 *>(wb.shadowRays) + (size_t)l * S, (uint32_t)S };
+        /* rays of plane k of a ray kind: whole rays, or directions beside the plane of the samples' origins */
+        auto planeSrc = [&](const DRay *rays, uint32_t k) {
+            if (!bp.splitRays) return whole(rays + (size_t)k * S);
+            return RaySource{ reinterpret_cast<const DRay *>(wb.origins), reinterpret_cast<const float4 *>(rays) + (size_t)k * S, (uint32_t)S };
         };
-        if (bp.count == bp.stride) { trace(whole(wb.bsdfRays), (uint64_t)S * nB, false, wb.bsdfHits, KKD_RAYS_BSDF); launches[KKD_STAGE_BSDF]++; }
-        else for (uint32_t b = 0; b < nB; ++b) { trace(whole(wb.bsdfRays + (size_t)b * S), bp.count, false, wb.bsdfHits + (size_t)b * S, KKD_RAYS_BSDF); launches[KKD_STAGE_BSDF]++; }
+        auto shadowSrc = [&](uint32_t l) { return planeSrc(wb.shadowRays, l); };
+        if (bp.count == bp.stride) { trace(planeSrc(wb.bsdfRays, 0), (uint64_t)S * nB, false, wb.bsdfHits, KKD_RAYS_BSDF); launches[KKD_STAGE_BSDF]++; }
+        else for (uint32_t b = 0; b < nB; ++b) { trace(planeSrc(wb.bsdfRays, b), bp.count, false, wb.bsdfHits + (size_t)b * S, KKD_RAYS_BSDF); launches[KKD_STAGE_BSDF]++; }
         if (timeStages) hipEventRecord(ctx->events[ev++], st);
         if (bp.count == bp.stride) { trace(shadowSrc(0), (uint64_t)S * nL, true, wb.occluded, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++; }
         else for (uint32_t l = 0; l < nL; ++l) { trace(shadowSrc(l), bp.count, true, (uint32_t *)wb.occluded + (size_t)l * S, KKD_RAYS_SHADOW); launches[KKD_STAGE_SHADOW]++; }

@@ -23,7 +23,7 @@ struct BatchParams {
      * group(w0) = (tile0 * bs^2 + pin0) * chunks + chunk0 */
     uint32_t chunk0, pin0, tile0, chunksShift /* log2(chunks) or 32 */, pixShift /* log2(bs^2) or 32 */;
     uint32_t nB, nL, hideEmitters;
-    uint32_t shadowShare;            /* shadow rays are stored as {direction, maxt} and start at the origin of the sample's first BSDF ray (RaySource) */
+    uint32_t splitRays;              /* direct plugins: BSDF and shadow rays are stored as float4 {direction, maxt} planes beside ONE plane of {shading point, mint} per sample (RaySource); path plugin: whole rays, its slots are compacted */
     uint32_t sampler, samplerDim, samplerSet;   /* KKD_SAMPLER_*; 'dimension'; size of the per-pixel point sets (ldsampler: a power of two, stratified: samplerRes^2) */
     uint32_t samplerRes;             /* stratified: cells per side (stratified.cpp:64-74) */
     HaltonSetup halton;              /* KKD_SAMPLER_HALTON / _HALTON_PLAIN / _HAMMERSLEY* */
@@ -49,18 +49,19 @@ struct WaveBuffers {
     uint8_t *aflags;     /* direct plugins: 1 = accum[i] is stored; 0 = it is (0, 0, 0, 1), the camera ray hit a surface that does not emit, and was not written [stride] */
     float4 *refN;        /* path plugin only: DirectSamplingRecord::refN; w = relative index of refraction along the path [stride] */
     uint8_t *bflags;     /* direct plugins: all a BSDF sample needs of refN, 1 = dot(wo, refN) >= 0 (the test of Emitter::pdfDirect of the shape emitters) [nB * stride] */
-    DRay *bsdfRays;      /*                                    [nB * stride] */
+    DRay *bsdfRays;      /* splitRays: float4 {direction, maxt} instead [nB * stride] */
+    float4 *origins;     /* splitRays: {shading point, mint}    [stride]      */
     DHit *bsdfHits;      /*                                    [nB * stride] */
     float4 *brec0;       /* bsdf weight rgb, +-pdf (<0: delta) [nB * stride] */
-    DRay *shadowRays;    /* BatchParams::shadowShare: float4 {direction, maxt} instead [nL * stride] */
+    DRay *shadowRays;    /* splitRays: float4 {direction, maxt} instead [nL * stride] */
     uint32_t *occluded;  /*                                    [nL * stride] */
     float4 *lrec;        /* MIS-weighted light contribution    [nL * stride] */
     uint32_t *sampleIdx; /* path plugin: sample (index into accum) of the path in this slot [stride] */
 };
 
-/* Where a traversal launch reads its rays.  dirs == nullptr: ray k = rays[k].  Otherwise ray k takes direction and maxt
- * from dirs[k] and origin and mint from rays[k mod stride]: the shadow rays of a sample start where its first BSDF ray
- * starts (the shading point), so kShade stores that point once (16 bytes less written per shadow ray). */
+/* Where a traversal launch reads its rays.  dirs == nullptr: ray k = rays[k].  Otherwise (BatchParams::splitRays) ray k takes
+ * direction and maxt from dirs[k] and origin and mint from origins[k mod stride], a float4 plane that `rays` points to: the
+ * BSDF and shadow rays of a sample all start at its shading point, which kShade stores once. */
 struct RaySource { const DRay *rays; const float4 *dirs; uint32_t stride; };
 
 void launchPrimary(hipStream_t st, bool count, const DScene &sc, const BatchParams &bp, DHit *hits, DeviceCounters *ctr);

@@ -192,7 +192,7 @@ template <bool SHARE>
 __device__ __forceinline__ DRay loadRay(const DRay *__restrict__ rays, const float4 *__restrict__ dirs, uint32_t stride, uint64_t k) {
     if (!SHARE) return rays[k];
     const uint32_t k32 = (uint32_t)k, oi = k32 < stride ? k32 : k32 % stride;
-    const float4 o = reinterpret_cast<const float4 *>(rays)[2 * (size_t)oi], d = dirs[k];
+    const float4 o = reinterpret_cast<const float4 *>(rays)[oi], d = dirs[k];
     DRay r; r.ox = o.x; r.oy = o.y; r.oz = o.z; r.mint = o.w; r.dx = d.x; r.dy = d.y; r.dz = d.z; r.maxt = d.w;
     return r;
 }
@@ -482,10 +482,10 @@ __device__ __forceinline__ void storeRay(DRay *dst, const DRay &r) {
     p[0] = make_float4(r.ox, r.oy, r.oz, r.mint); p[1] = make_float4(r.dx, r.dy, r.dz, r.maxt);
 }
 
-/* kShade's shadow rays: whole, or (BatchParams::shadowShare) direction and maxt only -- the origin is the first BSDF ray's */
-__device__ __forceinline__ void storeShadowRay(const WaveBuffers &wb, const BatchParams &bp, size_t slot, const DRay &r) {
-    if (bp.shadowShare) reinterpret_cast<float4 *>(wb.shadowRays)[slot] = make_float4(r.dx, r.dy, r.dz, r.maxt);
-    else storeRay(wb.shadowRays + slot, r);
+/* kShade's rays: whole, or (BatchParams::splitRays) direction and maxt only -- the origin is the sample's, stored once */
+__device__ __forceinline__ void storeRayOrDir(DRay *plane, const BatchParams &bp, size_t slot, const DRay &r) {
+    if (bp.splitRays) reinterpret_cast<float4 *>(plane)[slot] = make_float4(r.dx, r.dy, r.dz, r.maxt);
+    else storeRay(plane + slot, r);
 }
 
 #ifndef KKD_SHADE_WAVES
@@ -515,8 +515,9 @@ __global__ void __launch_bounds__(KKD_SHADE_BLOCK, KKD_SHADE_WAVES * 256 / KKD_S
     }
     if (!shade) {
         DRay dead; killRay(dead);
-        for (uint32_t b = 0; b < nB; ++b) { storeRay(wb.bsdfRays + (size_t)b * bp.stride + i, dead); wb.brec0[(size_t)b * bp.stride + i] = make_float4(0.f, 0.f, 0.f, 0.f); }
-        for (uint32_t l = 0; l < nL; ++l) { storeShadowRay(wb, bp, (size_t)l * bp.stride + i, dead); wb.lrec[(size_t)l * bp.stride + i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        if (bp.splitRays) wb.origins[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t b = 0; b < nB; ++b) { storeRayOrDir(wb.bsdfRays, bp, (size_t)b * bp.stride + i, dead); wb.brec0[(size_t)b * bp.stride + i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        for (uint32_t l = 0; l < nL; ++l) { storeRayOrDir(wb.shadowRays, bp, (size_t)l * bp.stride + i, dead); wb.lrec[(size_t)l * bp.stride + i] = make_float4(0.f, 0.f, 0.f, 0.f); }
         /* a camera ray that left the scene: kEnvMiss adds the environment to what is stored here */
         if (bp.integrator == KKD_INTEGRATOR_PATH || s.active) wb.accum[i] = accum;
         if (bp.integrator != KKD_INTEGRATOR_PATH) wb.aflags[i] = s.active ? 1u : 0u;
@@ -531,6 +532,7 @@ __global__ void __launch_bounds__(KKD_SHADE_BLOCK, KKD_SHADE_WAVES * 256 / KKD_S
     }
     const uint32_t btype = sc.materials[its.material].typeFlags;
     const f3 refN = (btype & (ETransmission | EBackSide)) ? f3(0.f) : its.sh.n;   /* DirectSamplingRecord(its) */
+    if (bp.splitRays) wb.origins[i] = make_float4(its.p.x, its.p.y, its.p.z, kEpsilon);   /* every ray of the sample starts here (scene.cpp:840-841 for the shadow rays) */
     const float cB = fdiv((float)nB, (float)(nB + nL)), cL = fdiv((float)nL, (float)(nB + nL));            /* :163-166 */
     const float invNL = frcp((float)nL);
     /* sibling integrator on the same kernels: MIDirectIntegrator::Li (integrators/direct/direct.cpp:176-311) draws the
@@ -553,7 +555,6 @@ __global__ void __launch_bounds__(KKD_SHADE_BLOCK, KKD_SHADE_WAVES * 256 / KKD_S
         woLocal = f3(0.f); bsdfPdf = 0.f; sampledType = 0u;
         const f3 bsdfVal = ablation(bp, 8u) ? f3(0.f) : sampleBsdf(sc, its.material, its.wi, u, woLocal, bsdfPdf, sampledType);   /* ($KKD_DEBUG bit 8, ablation build: no BSDF sampling) */
         DRay r; killRay(r);
-        if (bp.shadowShare && b == 0u) { r.ox = its.p.x; r.oy = its.p.y; r.oz = its.p.z; r.mint = kEpsilon; }   /* the shadow rays start here too (RaySource); maxt < 0: still no ray */
         float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!isZero(bsdfVal) && !dead) {
             const f3 wo = its.sh.toWorld(woLocal);
@@ -564,7 +565,7 @@ __global__ void __launch_bounds__(KKD_SHADE_BLOCK, KKD_SHADE_WAVES * 256 / KKD_S
                 if (sampledType == EDeltaTransmission) { const float e = sc.materials[its.material].eta; pathEta = its.wi.z > 0.f ? e : frcp(e); }   /* bRec.eta, dielectric.cpp:300-308 */
             }
         }
-        storeRay(wb.bsdfRays + (size_t)b * bp.stride + i, r);
+        storeRayOrDir(wb.bsdfRays, bp, (size_t)b * bp.stride + i, r);
         wb.brec0[(size_t)b * bp.stride + i] = rec;
         /* kResolve needs refN only for the sign test of the emitters' pdfDirect on this ray: one byte instead of the normal */
         if (bp.integrator != KKD_INTEGRATOR_PATH) wb.bflags[(size_t)b * bp.stride + i] = dot(f3(r.dx, r.dy, r.dz), refN) >= 0.f ? 1u : 0u;
@@ -600,7 +601,7 @@ __global__ void __launch_bounds__(KKD_SHADE_BLOCK, KKD_SHADE_WAVES * 256 / KKD_S
                 }
             }
         }
-        storeShadowRay(wb, bp, (size_t)l * bp.stride + i, r);
+        storeRayOrDir(wb.shadowRays, bp, (size_t)l * bp.stride + i, r);
         wb.lrec[(size_t)l * bp.stride + i] = rec;
     }
     /* most camera rays hit a surface that does not emit: their (0, 0, 0, 1) is a flag byte, not 16 bytes written here and read by kResolve */
@@ -857,7 +858,11 @@ __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveB
             DHit h = wb.bsdfHits[(size_t)b * bp.stride + i];
             if (h.id != kNoHit && (h.id & kHitNotEmitter)) continue;   /* hit a surface that does not emit: Le = 0 */
             if (h.id == kNoHit && sc.envEmitter < 0) continue;
-            const DRay r = wb.bsdfRays[(size_t)b * bp.stride + i];
+            DRay r;
+            if (bp.splitRays) {
+                const float4 o = wb.origins[i], d = reinterpret_cast<const float4 *>(wb.bsdfRays)[(size_t)b * bp.stride + i];
+                r.ox = o.x; r.oy = o.y; r.oz = o.z; r.mint = o.w; r.dx = d.x; r.dy = d.y; r.dz = d.z; r.maxt = d.w;
+            } else r = wb.bsdfRays[(size_t)b * bp.stride + i];
             const f3 rd(r.dx, r.dy, r.dz);
             DirectRec dRec; dRec.ref = f3(r.ox, r.oy, r.oz);
             /* pdfDirect only asks for the sign of dot(d, refN): the direct plugins carry that bit (kShade), the path plugin the normal */
@@ -1038,7 +1043,7 @@ void launchPrimary(hipStream_t st, bool count, const DScene &sc, const BatchPara
 
 template <bool ANY, bool COUNT, int OUT>
 static void launchTraceT(hipStream_t st, const DScene &sc, const RaySource &rays, uint64_t n, void *out, DeviceCounters *ctr, int cls) {
-    constexpr bool canShare = ANY && OUT == 2;       /* only the render path's shadow rays come without origins */
+    constexpr bool canShare = (ANY && OUT == 2) || (!ANY && OUT == 0);       /* only the render path's rays come without origins */
 #define KKD_LT(P, S) hipLaunchKernelGGL((kTrace<ANY, COUNT, OUT, P, kStackLds, 256, S>), dim3(blocksFor(n, 256)), dim3(256), 0, st, sc.nodes, sc.tris, sc.projTris, rays.rays, rays.dirs, rays.stride, n, out, ctr, cls)
     if (canShare && rays.dirs) { if (sc.projTris) KKD_LT(true, canShare); else KKD_LT(false, canShare); }
     else { if (sc.projTris) KKD_LT(true, false); else KKD_LT(false, false); }
@@ -1096,6 +1101,9 @@ void launchTracePhased(hipStream_t st, const DScene &sc, const RaySource &rays, 
     if (anyHit && rays.dirs) {
         if (count) { if (proj) launchPhasedT<true, true, 2, true, true>(st, sc, rays, n, out, ctr, cls, cont); else launchPhasedT<true, true, 2, false, true>(st, sc, rays, n, out, ctr, cls, cont); }
         else { if (proj) launchPhasedT<true, false, 2, true, true>(st, sc, rays, n, out, ctr, cls, cont); else launchPhasedT<true, false, 2, false, true>(st, sc, rays, n, out, ctr, cls, cont); }
+    } else if (rays.dirs) {
+        if (count) { if (proj) launchPhasedT<false, true, 0, true, true>(st, sc, rays, n, out, ctr, cls, cont); else launchPhasedT<false, true, 0, false, true>(st, sc, rays, n, out, ctr, cls, cont); }
+        else { if (proj) launchPhasedT<false, false, 0, true, true>(st, sc, rays, n, out, ctr, cls, cont); else launchPhasedT<false, false, 0, false, true>(st, sc, rays, n, out, ctr, cls, cont); }
     } else if (anyHit) {
         if (count) { if (proj) KKD_PH(true, true, 2, true); else KKD_PH(true, true, 2, false); }
         else { if (proj) KKD_PH(true, false, 2, true); else KKD_PH(true, false, 2, false); }
