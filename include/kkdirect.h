@@ -504,6 +504,25 @@ int kkd_mesh_save_serialized(const char *path, const kkd_mesh *meshes, uint32_t 
  * triangles and quads (a quad becomes (0,1,2) + (3,0,2)); properties of other types are skipped as libply does. */
 int kkd_mesh_load_ply(const char *path, const float *to_world, int32_t srgb, kkd_mesh *out);
 
+/* The obj plugin's reader, WavefrontOBJ::WavefrontOBJ + parse + createMesh (src/shapes/obj.cpp:165-349, 373-392, 586-717): "v" /
+ * "vn" / "vt" lists, faces "p", "p/t", "p//n", "p/t/n" with 1-based or negative (relative) indices, n-gons as fans, one mesh per
+ * geometry that a "g" or "usemtl" line (or the end of the file) closes, corners merged when position, normal and uv are equal
+ * after toWorld; mesh names as the plugin forms them (both "g" conventions, "_<index>" for repeats).  A file holds
+ * kkd_mesh_count_obj meshes, numbered in the order the plugin creates them with shapeIndex = -1; mesh_index selects one, and
+ * `material` (may be NULL) receives the "usemtl" name in force, which WavefrontOBJ::addChild matches BSDF names against
+ * (obj.cpp:738-757).  The plugin's 'shapeIndex' = s >= 0 is not simply "mesh s": the meshes closed by a "g" / "usemtl" line are
+ * created when their number equals s, but the one the END of the file closes is tested against the number of meshes closed
+ * before it minus one (obj.cpp:332), so it is created together with mesh count - 2 and never under its own number.
+ * *eof_mesh (may be NULL) says whether the last mesh was closed by the end of the file, so that an adapter can reproduce
+ * that; the Python mirror's obj_shape_index_meshes() spells the rule out.  flags: KKD_OBJ_*.  'faceNormals' is KKD_MESH_FACE_NORMALS
+ * on the loaded mesh, 'maxSmoothAngle' kkd_mesh_rebuild_topology (obj.cpp:336-343).  Not read: "mtllib" -- the material
+ * library would create phong / bitmap-texture BSDFs, which are outside this library's BSDF set; pass the scene's own BSDFs.
+ * 'flipNormals' is not offered by any of the loaders. */
+#define KKD_OBJ_COLLAPSE         1u   /* 'collapse': ignore "g" / "usemtl" boundaries, one mesh */
+#define KKD_OBJ_KEEP_TEXCOORD_V  2u   /* 'flipTexCoords' = false (the plugin's default stores v as 1 - v, obj.cpp:211, 306-307) */
+int kkd_mesh_count_obj(const char *path, uint32_t flags, uint32_t *count, uint32_t *eof_mesh);
+int kkd_mesh_load_obj(const char *path, uint32_t mesh_index, const float *to_world, uint32_t flags, kkd_mesh *out, char *material, uint32_t material_capacity);
+
 /* The 'maxSmoothAngle' parameter of the mesh plugins (src/shapes/ply.cpp:124-128, serialized.cpp:204-208, obj.cpp:336-342):
  * TriMesh::rebuildTopology (src/librender/trimesh.cpp:472-610) on a loaded mesh, in place -- vertices shared by faces whose
  * normals differ by more than max_angle_deg are split, the others merged (keyed by position, uv and colour); stored normals

@@ -663,6 +663,148 @@ def load_ply(path, to_world=None, srgb=True):
             "indices": np.array(tris, np.uint32), "face_normals": False}
 
 
+def load_obj(path, to_world=None, collapse=False, flip_tex_coords=True):
+    """WavefrontOBJ's reader (reference src/shapes/obj.cpp:165-349, 373-392, 586-717), written for clarity, not speed: returns
+    (meshes, eof_mesh) -- every mesh the plugin creates with shapeIndex = -1, in order, as dicts with "name" and "material", and
+    whether the last one was closed by the end of the file.  Raises ValueError where the plugin logs an error."""
+    f32 = np.float32
+    text = open(path, "rb").read().decode("latin-1")
+    raw = text.split("\n")
+    if raw and raw[-1] == "":
+        raw.pop()                                   # std::getline does not return an empty line after the final newline
+    stem = os.path.basename(path)
+    if "." in stem[1:]:
+        stem = stem[:stem.rindex(".")]
+    pos_in = [0]
+
+    def fetch():                                    # fetch_line, obj.cpp:165-187
+        if pos_in[0] >= len(raw):
+            return None
+        line = raw[pos_in[0]]; pos_in[0] += 1
+        if line == "":
+            return line
+        stripped = line.rstrip("\r\n\t ")
+        if stripped.endswith("\\"):
+            nxt = fetch()
+            return stripped[:-1] + (nxt if nxt is not None else "")
+        return stripped
+
+    def num(tok, k):
+        try:
+            return f32(float(tok[k]))
+        except (IndexError, ValueError):
+            return f32(0)
+
+    V, N, T, tris, geoms, seen = [], [], [], [], [], []
+    name, material, geom_index, name_before = stem, "", 0, False
+
+    def corner(tok):                                # parse(), obj.cpp:373-392
+        parts = [q for q in tok.split("/") if q != ""]
+        def ai(x):                                  # atoi: leading integer, 0 when there is none
+            import re
+            mm = re.match(r"\s*[+-]?\d+", x)
+            return int(mm.group(0)) if mm else 0
+        if len(parts) == 1:
+            return ai(parts[0]), 0, 0
+        if len(parts) == 2:
+            return (ai(parts[0]), ai(parts[1]), 0) if "//" not in tok else (ai(parts[0]), 0, ai(parts[1]))
+        if len(parts) == 3:
+            return ai(parts[0]), ai(parts[1]), ai(parts[2])
+        raise ValueError("Invalid OBJ face format!")
+
+    def close(as_name):
+        geoms.append({"name": as_name, "material": material, "tris": list(tris), "counts": (len(V), len(N), len(T))})
+        del tris[:]
+
+    while True:
+        line = fetch()
+        if line is None:
+            break
+        tok = line.split()
+        if not tok:
+            continue
+        key = tok[0]
+        if key == "v":
+            V.append([num(tok, 1), num(tok, 2), num(tok, 3)])
+        elif key == "vn":
+            N.append([num(tok, 1), num(tok, 2), num(tok, 3)])
+        elif key == "g" and not collapse:
+            new_name = line[1:].strip(" \t\r\n")
+            target = name if name_before else new_name
+            if tris:
+                if target in seen:
+                    target = "%s_%i" % (target, geom_index)
+                geom_index += 1; seen.append(target); close(target)
+            else:
+                name_before = True
+            name = new_name
+        elif key == "usemtl":
+            if tris and not collapse:
+                if name in seen:
+                    name = "%s_%i" % (name, geom_index)
+                geom_index += 1; seen.append(name); close(name)
+                name = stem
+            material = line[6:].strip(" \t\r\n")
+        elif key == "vt":
+            u, v = num(tok, 1), num(tok, 2)
+            T.append([u, f32(1) - v if flip_tex_coords else v])
+        elif key == "f":
+            cs = tok[1:]
+            last = ""
+            first3 = []
+            for k in range(3):                      # a missing token repeats the one before (the stream leaves tmp untouched)
+                if k < len(cs):
+                    last = cs[k]
+                first3.append(corner(last))
+            tris.append(tuple(first3))
+            cur = list(first3)
+            for extra in cs[3:]:
+                cur = [cur[0], cur[2], corner(extra)]
+                tris.append(tuple(cur))
+    if name in seen:
+        name = "%s_%i" % (stem, geom_index)
+    eof_mesh = bool(tris)
+    if tris:
+        close(name)
+
+    meshes = []
+    for g in geoms:                                 # createMesh, obj.cpp:610-717
+        nv, nn, nt = g["counts"]
+        table, verts, idx = {}, [], []
+        has_n = has_uv = False
+        for tri in g["tris"]:
+            for (vi, ti, ni) in tri:
+                if vi < 0: vi += nv + 1
+                if ni < 0: ni += nn + 1
+                if ti < 0: ti += nt + 1
+                if vi > nv or vi <= 0:
+                    raise ValueError("Out of bounds: tried to access vertex %i (max: %i)" % (vi, nv))
+                p = np.array([V[vi - 1]], f32); n = np.zeros((1, 3), f32); uv = (f32(0), f32(0))
+                if ni != 0:
+                    if ni > nn or ni < 0:
+                        raise ValueError("Out of bounds: tried to access normal %i (max: %i)" % (ni, nn))
+                    n = np.array([N[ni - 1]], f32); has_n = True
+                if to_world is not None and not np.array_equal(np.asarray(to_world, f32).reshape(4, 4), np.eye(4, dtype=f32)):
+                    p, n2, _ = _xform(to_world, p, n if ni != 0 else None)
+                    if ni != 0: n = n2
+                elif ni != 0:
+                    ln = np.sqrt((n * n).sum(dtype=f32), dtype=f32)
+                    if ln > 0: n = (n / ln).astype(f32)
+                if ti != 0:
+                    if ti > nt or ti < 0:
+                        raise ValueError("Out of bounds: tried to access uv %i (max: %i)" % (ti, nt))
+                    uv = tuple(T[ti - 1]); has_uv = True
+                k = tuple(float(x) for x in p[0]) + tuple(float(x) for x in n[0]) + (float(uv[0]), float(uv[1]))
+                if k not in table:
+                    table[k] = len(verts); verts.append(k)
+                idx.append(table[k])
+        va = np.array(verts, f32).reshape(-1, 8)
+        meshes.append({"name": g["name"], "material": g["material"], "positions": va[:, 0:3].copy(),
+                       "normals": va[:, 3:6].copy() if has_n else None, "texcoords": va[:, 6:8].copy() if has_uv else None,
+                       "colors": None, "indices": np.array(idx, np.uint32).reshape(-1, 3), "face_normals": False})
+    return meshes, eof_mesh
+
+
 def rebuild_topology(mesh, max_angle_deg):
     """TriMesh::rebuildTopology (reference src/librender/trimesh.cpp:472-610), the 'maxSmoothAngle' parameter of the mesh
     plugins, corner by corner in float32 like the reference's Float (slow; small test meshes only).  mesh: dict as

@@ -6,6 +6,7 @@
  *   TriMesh::serialize(Stream*)  (the .serialized writer, version 4)             src/librender/trimesh.cpp:1060-1108
  *   SerializedMesh (toWorld, winding flip for mirroring transforms)              src/shapes/serialized.cpp:150-206
  *   PLYLoader (vertex / face callbacks, quad split, sRGB vertex colours)        src/shapes/ply.cpp:96-330, 326-470
+ *   WavefrontOBJ (statement loop, corner forms, createMesh)                     src/shapes/obj.cpp:165-349, 373-392, 586-717
  *
  * The file is memory-mapped and the deflate stream is inflated straight into the destination arrays (no intermediate
  * copy of a >= 10 M-triangle scan); the arrays are what kkd_scene_desc points at.
@@ -19,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -488,6 +490,206 @@ int kkd_mesh_load_ply(const char *path, const float *to_world, int32_t srgb, kkd
     if (stem.find_last_of('.') != std::string::npos) stem = stem.substr(0, stem.find_last_of('.'));
     std::snprintf(out->name, sizeof(out->name), "%s", stem.c_str());  /* m_name = filePath.stem(), ply.cpp:99 */
     finishAabb(out);
+    return KKD_OK;
+}
+
+} /* extern "C" */
+
+namespace {
+
+/* ---- Wavefront OBJ: the obj plugin's reader (src/shapes/obj.cpp:165-349, 373-392, 586-717) -------------------------------
+ * One pass over the file as the plugin's constructor makes it: "v" / "vn" / "vt" grow three global lists, "f" appends
+ * triangles (n-gons as fans), "g" and "usemtl" close the current geometry when it holds triangles, and every geometry that
+ * is closed becomes one TriMesh through createMesh (corner = (position, normal, uv) AFTER toWorld, equal corners merged
+ * through an ordered map).  Quirks kept because a drop-in must name and split meshes the same way: both naming conventions
+ * of "g" (name before or after the geometry), "_<index>" suffixes for repeated names, substr(1) / substr(6) of the raw line
+ * for the names, a face with fewer than three corners repeating its last token, backslash line continuation. */
+struct ObjTri { int p[3], n[3], uv[3]; };
+struct ObjGeom { std::string name, material; std::vector<ObjTri> tris; size_t nV = 0, nN = 0, nT = 0; /* list sizes when it was closed */ };
+struct ObjFile { std::vector<float> v, vn, vt; std::vector<ObjGeom> geoms; bool eofMesh = false; /* the last geometry was closed by the end of the file */ };
+
+std::string objTrim(const std::string &s) {            /* mitsuba::trim, src/libcore/util.cpp: blanks, tabs, CR, LF */
+    const char *ws = " \t\r\n";
+    const size_t a = s.find_first_not_of(ws);
+    if (a == std::string::npos) return "";
+    return s.substr(a, s.find_last_not_of(ws) - a + 1);
+}
+
+struct ObjLines {                                      /* fetch_line, obj.cpp:165-187 */
+    const char *p, *end;
+    bool raw(std::string &line) { if (p >= end) return false; const char *q = (const char *)std::memchr(p, '\n', (size_t)(end - p)); if (!q) q = end; line.assign(p, q); p = q < end ? q + 1 : end; return true; }
+    bool fetch(std::string &line) {
+        if (!raw(line)) return false;
+        if (line.empty()) return true;
+        int last = (int)line.size() - 1;
+        while (last >= 0 && (line[last] == '\r' || line[last] == '\n' || line[last] == '\t' || line[last] == ' ')) --last;
+        if (last >= 0 && line[last] == '\\') { std::string next; fetch(next); line = line.substr(0, (size_t)last) + next; }
+        else line.resize((size_t)(last + 1));
+        return true;
+    }
+};
+
+struct ObjTokens {                                     /* std::istringstream >> std::string */
+    const std::string &s; size_t pos = 0;
+    explicit ObjTokens(const std::string &str) : s(str) {}
+    bool next(std::string &tok) {
+        while (pos < s.size() && std::isspace((unsigned char)s[pos])) ++pos;
+        if (pos >= s.size()) return false;
+        const size_t a = pos;
+        while (pos < s.size() && !std::isspace((unsigned char)s[pos])) ++pos;
+        tok.assign(s, a, pos - a);
+        return true;
+    }
+    float number() { std::string t; if (!next(t)) return 0.f; return std::strtof(t.c_str(), nullptr); }
+};
+
+bool objCorner(ObjTri &t, int i, const std::string &str) {      /* parse(), obj.cpp:373-392; tokenize() drops empty tokens */
+    std::vector<std::string> tok; size_t a = 0;
+    while (a <= str.size()) {
+        const size_t b = str.find('/', a);
+        const std::string part = str.substr(a, b == std::string::npos ? std::string::npos : b - a);
+        if (!part.empty()) tok.push_back(part);
+        if (b == std::string::npos) break;
+        a = b + 1;
+    }
+    if (tok.size() == 1) t.p[i] = std::atoi(tok[0].c_str());
+    else if (tok.size() == 2) {
+        t.p[i] = std::atoi(tok[0].c_str());
+        if (str.find("//") == std::string::npos) t.uv[i] = std::atoi(tok[1].c_str()); else t.n[i] = std::atoi(tok[1].c_str());
+    } else if (tok.size() == 3) { t.p[i] = std::atoi(tok[0].c_str()); t.uv[i] = std::atoi(tok[1].c_str()); t.n[i] = std::atoi(tok[2].c_str()); }
+    else return false;
+    return true;
+}
+
+int parseObj(const char *path, uint32_t flags, ObjFile &of) {
+    MappedFile f; std::string err;
+    if (!f.open(path, err)) return ioFail(err);
+    const bool collapse = (flags & KKD_OBJ_COLLAPSE) != 0, flipV = (flags & KKD_OBJ_KEEP_TEXCOORD_V) == 0;
+    std::string stem = path;
+    if (stem.find_last_of('/') != std::string::npos) stem = stem.substr(stem.find_last_of('/') + 1);
+    if (stem.find_last_of('.') != std::string::npos && stem.find_last_of('.') > 0) stem = stem.substr(0, stem.find_last_of('.'));   /* m_name = path.stem() */
+    ObjLines lines{ (const char *)f.p, (const char *)f.p + f.size };
+    std::string line, buf, name = stem, material;
+    std::vector<std::string> seen;                    /* geomNames */
+    auto taken = [&](const std::string &n) { return std::find(seen.begin(), seen.end(), n) != seen.end(); };
+    std::vector<ObjTri> tris;
+    int geomIndex = 0; bool nameBeforeGeometry = false;
+    auto close = [&](const std::string &as) {          /* createMesh's arguments at this point of the file */
+        ObjGeom g; g.name = as; g.material = material; g.tris.swap(tris); g.nV = of.v.size() / 3; g.nN = of.vn.size() / 3; g.nT = of.vt.size() / 2;
+        of.geoms.push_back(std::move(g)); tris.clear();
+    };
+    while (lines.fetch(line)) {
+        ObjTokens tk(line);
+        if (!tk.next(buf)) continue;
+        if (buf == "v") { for (int k = 0; k < 3; ++k) of.v.push_back(tk.number()); }
+        else if (buf == "vn") { for (int k = 0; k < 3; ++k) of.vn.push_back(tk.number()); }
+        else if (buf == "g" && !collapse) {
+            std::string target; const std::string newName = objTrim(line.substr(1));
+            target = nameBeforeGeometry ? name : newName;            /* obj.cpp:262-269: two conventions for where the name goes */
+            if (!tris.empty()) {
+                if (taken(target)) target += "_" + std::to_string(geomIndex);
+                geomIndex += 1; seen.push_back(target);
+                close(target);
+            } else nameBeforeGeometry = true;
+            name = newName;
+        } else if (buf == "usemtl") {
+            if (!tris.empty() && !collapse) {
+                if (taken(name)) name += "_" + std::to_string(geomIndex);
+                geomIndex += 1; seen.push_back(name);
+                close(name);
+                name = stem;
+            }
+            material = objTrim(line.substr(6));
+        } else if (buf == "vt") { const float u = tk.number(); float v = tk.number(); if (flipV) v = 1 - v; of.vt.push_back(u); of.vt.push_back(v); }
+        else if (buf == "f") {
+            std::string tmp; ObjTri t; std::memset(&t, 0, sizeof(t));
+            for (int k = 0; k < 3; ++k) { tk.next(tmp); if (!objCorner(t, k, tmp)) return ioFail("Invalid OBJ face format!"); }   /* a missing token leaves tmp as it was */
+            tris.push_back(t);
+            while (tk.next(tmp)) {                                   /* n-gons as fans, assuming a convex shape */
+                t.p[1] = t.p[2]; t.uv[1] = t.uv[2]; t.n[1] = t.n[2];
+                if (!objCorner(t, 2, tmp)) return ioFail("Invalid OBJ face format!");
+                tris.push_back(t);
+            }
+        }
+    }
+    if (taken(name)) name = stem + "_" + std::to_string(geomIndex);
+    if (!tris.empty()) { close(name); of.eofMesh = true; }
+    return KKD_OK;
+}
+
+int buildObjMesh(const ObjFile &of, const ObjGeom &g, const float *to_world, kkd_mesh *out) {     /* createMesh, obj.cpp:610-717 */
+    Xform x; x.set(to_world);
+    struct Key { float k[8]; bool operator<(const Key &o) const { for (int i = 0; i < 8; ++i) { if (k[i] < o.k[i]) return true; if (k[i] > o.k[i]) return false; } return false; } };
+    std::map<Key, uint32_t> merged; std::vector<Key> verts; std::vector<uint32_t> idx; idx.reserve(3 * g.tris.size());
+    bool hasN = false, hasUV = false;
+    char msg[128];
+    for (const ObjTri &t : g.tris)
+        for (int j = 0; j < 3; ++j) {
+            int vi = t.p[j], ni = t.n[j], ti = t.uv[j];
+            if (vi < 0) vi += (int)g.nV + 1;
+            if (ni < 0) ni += (int)g.nN + 1;
+            if (ti < 0) ti += (int)g.nT + 1;
+            if (vi > (int)g.nV || vi <= 0) { std::snprintf(msg, sizeof(msg), "Out of bounds: tried to access vertex %i (max: %i)", vi, (int)g.nV); return ioFail(msg); }
+            Key key; std::memset(&key, 0, sizeof(key));
+            key.k[0] = of.v[3 * (size_t)(vi - 1)]; key.k[1] = of.v[3 * (size_t)(vi - 1) + 1]; key.k[2] = of.v[3 * (size_t)(vi - 1) + 2];
+            if (!x.identity) x.point(key.k);
+            if (ni != 0) {
+                if (ni > (int)g.nN || ni < 0) { std::snprintf(msg, sizeof(msg), "Out of bounds: tried to access normal %i (max: %i)", ni, (int)g.nN); return ioFail(msg); }
+                float *n = key.k + 3; n[0] = of.vn[3 * (size_t)(ni - 1)]; n[1] = of.vn[3 * (size_t)(ni - 1) + 1]; n[2] = of.vn[3 * (size_t)(ni - 1) + 2];
+                if (!x.identity) x.normal(n);                        /* objectToWorld(Normal), then normalize unless zero */
+                else { const float l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]); if (l > 0.f) { n[0] /= l; n[1] /= l; n[2] /= l; } }
+                hasN = true;
+            }
+            if (ti != 0) {
+                if (ti > (int)g.nT || ti < 0) { std::snprintf(msg, sizeof(msg), "Out of bounds: tried to access uv %i (max: %i)", ti, (int)g.nT); return ioFail(msg); }
+                key.k[6] = of.vt[2 * (size_t)(ti - 1)]; key.k[7] = of.vt[2 * (size_t)(ti - 1) + 1];
+                hasUV = true;
+            }
+            auto it = merged.find(key);
+            uint32_t id;
+            if (it != merged.end()) id = it->second; else { id = (uint32_t)verts.size(); merged.emplace(key, id); verts.push_back(key); }
+            idx.push_back(id);
+        }
+    out->n_verts = verts.size(); out->n_tris = g.tris.size();
+    out->positions = allocArray<float>(3 * verts.size()); out->indices = allocArray<uint32_t>(idx.size());
+    if (hasN) out->normals = allocArray<float>(3 * verts.size());
+    if (hasUV) out->texcoords = allocArray<float>(2 * verts.size());
+    if (!out->positions || !out->indices || (hasN && !out->normals) || (hasUV && !out->texcoords)) { kkd_mesh_free(out); g_globalError = "OBJ: out of memory"; return KKD_ERR_NOMEM; }
+    for (size_t v = 0; v < verts.size(); ++v) {
+        std::memcpy(out->positions + 3 * v, verts[v].k, 12);
+        if (hasN) std::memcpy(out->normals + 3 * v, verts[v].k + 3, 12);
+        if (hasUV) std::memcpy(out->texcoords + 2 * v, verts[v].k + 6, 8);
+    }
+    std::memcpy(out->indices, idx.data(), idx.size() * sizeof(uint32_t));
+    std::snprintf(out->name, sizeof(out->name), "%s", g.name.c_str());
+    finishAabb(out);
+    return KKD_OK;
+}
+
+} /* namespace */
+
+extern "C" {
+
+int kkd_mesh_count_obj(const char *path, uint32_t flags, uint32_t *count, uint32_t *eof_mesh) {
+    if (!path || !count) return ioFail("kkd_mesh_count_obj: null argument");
+    ObjFile of;
+    const int rc = parseObj(path, flags, of);
+    if (rc != KKD_OK) return rc;
+    *count = (uint32_t)of.geoms.size();
+    if (eof_mesh) *eof_mesh = of.eofMesh ? 1u : 0u;
+    return KKD_OK;
+}
+
+int kkd_mesh_load_obj(const char *path, uint32_t mesh_index, const float *to_world, uint32_t flags, kkd_mesh *out, char *material, uint32_t material_capacity) {
+    if (!path || !out) return ioFail("kkd_mesh_load_obj: null argument");
+    resetMesh(out);
+    ObjFile of;
+    int rc = parseObj(path, flags, of);
+    if (rc != KKD_OK) return rc;
+    if (mesh_index >= of.geoms.size()) return ioFail("kkd_mesh_load_obj: mesh index " + std::to_string(mesh_index) + " out of range (the file holds " + std::to_string(of.geoms.size()) + ")");
+    rc = buildObjMesh(of, of.geoms[mesh_index], to_world, out);
+    if (rc != KKD_OK) return rc;
+    if (material && material_capacity) std::snprintf(material, material_capacity, "%s", of.geoms[mesh_index].material.c_str());
     return KKD_OK;
 }
 

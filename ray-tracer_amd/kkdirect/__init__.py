@@ -399,6 +399,46 @@ def load_ply(path, to_world=None, srgb=True, max_smooth_angle=None):
         lib.kkd_mesh_free(C.byref(m))
 
 
+def _obj_flags(collapse, flip_tex_coords):
+    return (abi.OBJ_COLLAPSE if collapse else 0) | (0 if flip_tex_coords else abi.OBJ_KEEP_TEXCOORD_V)
+
+
+def obj_mesh_count(path, collapse=False):
+    """-> (number of meshes the obj plugin creates from the file with shapeIndex = -1, whether the last one is closed by the end
+    of the file); reference src/shapes/obj.cpp:244-334"""
+    n = C.c_uint32(0); eof = C.c_uint32(0)
+    _io_check(load_library().kkd_mesh_count_obj(os.fsencode(path), _obj_flags(collapse, True), C.byref(n), C.byref(eof)), "kkd_mesh_count_obj")
+    return int(n.value), bool(eof.value)
+
+
+def obj_shape_index_meshes(count, eof_mesh, shape_index):
+    """Which of a file's meshes the plugin's 'shapeIndex' parameter creates (reference src/shapes/obj.cpp:277, 293, 332): a mesh
+    closed by a "g" / "usemtl" line when its number equals shapeIndex; the mesh the end of the file closes when the number of
+    meshes closed BEFORE it, minus one, equals shapeIndex -- so it comes with mesh count - 2 and never under its own number."""
+    if shape_index < 0:
+        return list(range(count))
+    closed = count - 1 if eof_mesh else count
+    out = [shape_index] if shape_index < closed else []
+    if eof_mesh and closed - 1 == shape_index:
+        out.append(count - 1)
+    return out
+
+
+def load_obj(path, mesh_index=0, to_world=None, collapse=False, flip_tex_coords=True, max_smooth_angle=None):
+    """The obj shape plugin's reader (reference src/shapes/obj.cpp:165-349, 610-717) through kkd_mesh_load_obj; the returned
+    dict also carries "material", the usemtl name in force (what WavefrontOBJ::addChild matches BSDF names against)."""
+    lib = load_library(); m = abi.Mesh(); keep, ptr = _xf(to_world)
+    mat = C.create_string_buffer(256)
+    _io_check(lib.kkd_mesh_load_obj(os.fsencode(path), int(mesh_index), ptr, _obj_flags(collapse, flip_tex_coords), C.byref(m), mat, 256), "kkd_mesh_load_obj")
+    try:
+        _smooth(lib, m, max_smooth_angle)
+        d = _mesh_to_dict(m)
+        d["material"] = mat.value.decode(errors="replace")
+        return d
+    finally:
+        lib.kkd_mesh_free(C.byref(m))
+
+
 def save_serialized(path, meshes):
     """TriMesh::serialize(Stream*) (reference src/librender/trimesh.cpp:1060-1108); meshes: dicts as load_serialized returns."""
     lib = load_library(); arr = (abi.Mesh * len(meshes))(); keep = []

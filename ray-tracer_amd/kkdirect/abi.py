@@ -119,6 +119,7 @@ class Mesh(C.Structure):
 
 
 MESH_FACE_NORMALS = 1
+OBJ_COLLAPSE, OBJ_KEEP_TEXCOORD_V = 1, 2
 
 ENTRY_POINTS = {
     "kkd_device_count": (C.c_int, []),
@@ -151,6 +152,8 @@ ENTRY_POINTS = {
     "kkd_mesh_load_serialized": (C.c_int, [C.c_char_p, i32, pf32, C.POINTER(Mesh)]),
     "kkd_mesh_save_serialized": (C.c_int, [C.c_char_p, C.POINTER(Mesh), u32]),
     "kkd_mesh_load_ply": (C.c_int, [C.c_char_p, pf32, i32, C.POINTER(Mesh)]),
+    "kkd_mesh_count_obj": (C.c_int, [C.c_char_p, u32, pu32, pu32]),
+    "kkd_mesh_load_obj": (C.c_int, [C.c_char_p, u32, pf32, u32, C.POINTER(Mesh), C.c_char_p, u32]),
     "kkd_mesh_rebuild_topology": (C.c_int, [C.POINTER(Mesh), C.c_float]),
     "kkd_mesh_free": (None, [C.POINTER(Mesh)]),
     "kkd_request_cancel": (None, [C.c_void_p]),

@@ -293,3 +293,164 @@ def test_max_smooth_angle_excludes_face_normals(tmp_path):
     sc = Scene()
     with pytest.raises(ValueError, match="maxSmoothAngle"):
         sc.add_serialized(path, sc.diffuse(), face_normals=True, max_smooth_angle=30.0)
+
+
+# ---- Wavefront OBJ (reference src/shapes/obj.cpp) ------------------------------------------------------------------
+
+def _obj_all(path, **kw):
+    n, eof = kkdirect.obj_mesh_count(path, collapse=kw.get("collapse", False))
+    return [kkdirect.load_obj(path, i, **kw) for i in range(n)], eof
+
+
+def _same_obj(lib_meshes, ora_meshes, exact=True):
+    assert len(lib_meshes) == len(ora_meshes)
+    for a, b in zip(lib_meshes, ora_meshes):
+        assert a["name"] == b["name"] and a["material"] == b["material"], (a["name"], b["name"], a["material"], b["material"])
+        _same(a, b, exact)
+
+
+def test_obj_known_answer_quad(tmp_path):
+    """written out by hand from obj.cpp: a quad is a fan of two triangles, equal corners are merged, v is stored as 1 - v,
+    the mesh takes the file's stem as its name, normals are normalised"""
+    p = tmp_path / "quad.obj"
+    p.write_text("# a quad\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvn 0 0 2\nf 1/1/1 2/2/1 3/3/1 4/4/1\n")
+    assert kkdirect.obj_mesh_count(str(p)) == (1, True)
+    m = kkdirect.load_obj(str(p))
+    assert m["name"] == "quad" and m["material"] == ""
+    assert np.array_equal(m["indices"], [[0, 1, 2], [0, 2, 3]])
+    assert np.array_equal(m["positions"], np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], np.float32))
+    assert np.array_equal(m["texcoords"], np.array([[0, 1], [1, 1], [1, 0], [0, 0]], np.float32))
+    assert np.array_equal(m["normals"], np.tile(np.array([[0, 0, 1]], np.float32), (4, 1)))
+    m = kkdirect.load_obj(str(p), flip_tex_coords=False)
+    assert np.array_equal(m["texcoords"], np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32))
+
+
+def _obj_text(seed, crlf=False):
+    """a file that uses every form the reader knows: the four corner forms, negative indices, n-gons, both "g" naming
+    conventions are exercised by `lead_g`, usemtl splits, repeated names, a continued line, comments, unknown statements"""
+    rng = np.random.RandomState(seed)
+    L = ["# generated", "mtllib ignored.mtl", "o ignored"]
+    nv = 0
+
+    def grid(n):
+        nonlocal nv
+        pts = rng.rand(n * n, 3).round(3)
+        for q in pts:
+            L.append("v %g %g %g" % tuple(q))
+        base = nv; nv += n * n
+        return base
+    for k in range(6):
+        L.append("vn %g %g %g" % tuple(rng.normal(size=3).round(3)))
+    L.append("vn 0 0 0")
+    for k in range(5):
+        L.append("vt %g %g" % tuple(rng.rand(2).round(3)))
+    b = grid(3)
+    L.append("g first")
+    L.append("usemtl red")
+    L.append("f %d %d %d" % (b + 1, b + 2, b + 4))
+    L.append("f %d/1 %d/2 %d/3 %d/4" % (b + 2, b + 3, b + 6, b + 5))
+    L.append("f %d//1 %d//2 \\" % (b + 4, b + 5))
+    L.append("  %d//7" % (b + 7))
+    L.append("usemtl blue")
+    L.append("f %d/1/2 %d/2/3 %d/5/6 %d/3/1 %d/4/4" % (b + 5, b + 6, b + 9, b + 8, b + 7))
+    L.append("g second")
+    b2 = grid(2)
+    L.append("f -1 -2 -3")
+    L.append("f -4/-1/-1 -3/-2/-2 -1/-3/-3")
+    L.append("s off")
+    L.append("g first")
+    L.append("f %d %d %d" % (b2 + 1, b2 + 2, b2 + 3))
+    L.append("f %d %d" % (b2 + 1, b2 + 4))            # two corners: the last one repeats
+    L.append("g")
+    L.append("\tf %d %d %d" % (b + 1, b + 5, b + 9))
+    return ("\r\n" if crlf else "\n").join(L) + ("\r\n" if crlf else "\n")
+
+
+@pytest.mark.parametrize("seed,crlf,kw", [(1, False, {}), (2, True, {}), (3, False, {"collapse": True}), (4, False, {"flip_tex_coords": False}),
+                                          (5, True, {"to_world": "trs"}), (6, False, {"to_world": "mirror"})])
+def test_obj_load_matches_oracle(tmp_path, seed, crlf, kw):
+    p = tmp_path / "scan.model.obj"
+    p.write_bytes(_obj_text(seed, crlf).encode())
+    kw = dict(kw)
+    if kw.get("to_world") == "trs":
+        kw["to_world"] = (look_at((1, 2, 3), (0, 0.5, 0), (0, 1, 0)) @ np.diag([2.0, 0.5, 1.5, 1.0])).astype(np.float32)
+    elif kw.get("to_world") == "mirror":
+        kw["to_world"] = np.diag([-1.0, 1.0, 1.0, 1.0]).astype(np.float32)
+    lib, eof = _obj_all(str(p), **kw)
+    ora, ora_eof = kkoracle.load_obj(str(p), **kw)
+    assert eof == ora_eof
+    # under a transform the normals go through an inverse transpose that the two sides form in different precisions: last bit
+    _same_obj(lib, ora, exact="to_world" not in kw)
+    if kw.get("collapse"):
+        assert len(lib) == 1 and lib[0]["name"] == "scan.model" and lib[0]["material"] == "blue"
+    else:
+        # names as the plugin forms them: "g first" before any face = the name-before-geometry convention, so a mesh is saved
+        # under the name in force when its faces were read; the usemtl split falls back to the stem; the second "first" is
+        # numbered; the bare "g" leaves an empty name, which is not taken yet, so the last mesh keeps it (traced by hand through
+        # obj.cpp:258-334)
+        assert [m["name"] for m in lib] == ["first", "scan.model", "second", "first_3", ""], [m["name"] for m in lib]
+        assert [m["material"] for m in lib] == ["red", "blue", "blue", "blue", "blue"]
+        assert lib[0]["normals"] is not None and lib[0]["texcoords"] is not None     # one corner form with each is enough for the mesh
+        assert lib[3]["normals"] is None and lib[3]["texcoords"] is None
+        assert lib[3]["indices"].shape == (2, 3) and lib[3]["indices"][1][1] == lib[3]["indices"][1][2]
+
+
+def test_obj_name_after_geometry_convention(tmp_path):
+    """faces first, then "g name": the mesh that was just read takes the NEW name (obj.cpp:262-269)"""
+    p = tmp_path / "late.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nf 1 2 3\ng alpha\nf 2 4 3\ng beta\n")
+    lib, eof = _obj_all(str(p)); ora, ora_eof = kkoracle.load_obj(str(p))
+    _same_obj(lib, ora)
+    assert [m["name"] for m in lib] == ["alpha", "beta"] and eof is False and ora_eof is False
+    # the positions list is global: the second mesh only holds the three vertices it uses
+    assert lib[1]["positions"].shape == (3, 3)
+
+
+def test_obj_shape_index_rule():
+    """obj.cpp:277, 293, 332: the mesh the end of the file closes comes with number count - 2, never under its own"""
+    f = kkdirect.obj_shape_index_meshes
+    assert f(3, True, -1) == [0, 1, 2]
+    assert f(3, True, 0) == [0] and f(3, True, 1) == [1, 2] and f(3, True, 2) == []
+    assert f(1, True, 0) == [] and f(1, True, -1) == [0]
+    assert f(2, False, 1) == [1] and f(2, False, 0) == [0]
+
+
+def test_obj_errors(tmp_path):
+    def load(text, **kw):
+        p = tmp_path / "bad.obj"; p.write_text(text)
+        return kkdirect.load_obj(str(p), **kw)
+    tri = "v 0 0 0\nv 1 0 0\nv 0 1 0\n"
+    with pytest.raises(kkdirect.KKDError, match="tried to access vertex 4"):
+        load(tri + "f 1 2 4\n")
+    with pytest.raises(kkdirect.KKDError, match="tried to access vertex 0"):
+        load(tri + "f 1 2 0\n")
+    with pytest.raises(kkdirect.KKDError, match="tried to access normal 1"):
+        load(tri + "f 1//1 2//1 3//1\n")
+    with pytest.raises(kkdirect.KKDError, match="tried to access uv 2"):
+        load(tri + "vt 0 0\nf 1/2 2/1 3/1\n")
+    with pytest.raises(kkdirect.KKDError, match="Invalid OBJ face format"):
+        load(tri + "f 1/1/1/1 2 3\n")
+    with pytest.raises(kkdirect.KKDError, match="Invalid OBJ face format"):
+        load(tri + "f\n")
+    with pytest.raises(kkdirect.KKDError, match="out of range"):
+        load(tri + "f 1 2 3\n", mesh_index=1)
+    with pytest.raises(kkdirect.KKDError, match="cannot open"):
+        kkdirect.load_obj(str(tmp_path / "absent.obj"))
+    # a vertex defined AFTER the geometry was closed is out of bounds for it (the lists are read as they stand then)
+    with pytest.raises(kkdirect.KKDError, match="tried to access vertex 4"):
+        load(tri + "f 1 2 4\ng later\nv 1 1 0\nf 1 2 3\n")
+    for text in (tri + "f 1 2 4\n", tri + "f 1/1/1/1 2 3\n"):
+        p = tmp_path / "bad2.obj"; p.write_text(text)
+        with pytest.raises(ValueError):
+            kkoracle.load_obj(str(p))
+
+
+def test_obj_max_smooth_angle(tmp_path):
+    """a cube written face by face with shared corners: 8 vertices as read, 24 after maxSmoothAngle = 30 (obj.cpp:336-343)"""
+    c = [(x, y, z) for x in (0, 1) for y in (0, 1) for z in (0, 1)]
+    quads = [(1, 2, 4, 3), (5, 7, 8, 6), (1, 5, 6, 2), (3, 4, 8, 7), (1, 3, 7, 5), (2, 6, 8, 4)]
+    p = tmp_path / "cube.obj"
+    p.write_text("".join("v %d %d %d\n" % q for q in c) + "".join("f %d %d %d %d\n" % q for q in quads))
+    assert kkdirect.load_obj(str(p))["positions"].shape == (8, 3)
+    m = kkdirect.load_obj(str(p), max_smooth_angle=30)
+    assert m["positions"].shape == (24, 3) and m["indices"].shape == (12, 3) and m["normals"] is None
