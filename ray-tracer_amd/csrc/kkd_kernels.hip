@@ -646,17 +646,15 @@ __global__ void __launch_bounds__(256, 4) kPathBounce(DScene sc, BatchParams bp,
             Its its;
             bool cont = true, hitEmitter = false;
             f3 value(0.f);
+            float envPdf = 0.f; bool envLooked = false;   /* the environment's density in this direction, looked up together with its value */
             if (h.id == kNoHit) {                                                        /* :233-248 */
                 cont = false;
                 if (sc.envEmitter >= 0) {
-                    value = envEval(sc.env, rd);
+                    envEvalWithPdf(sc.env, rd, value, envPdf); envLooked = true;
                     const f3 center(sc.env.center[0], sc.env.center[1], sc.env.center[2]);
                     float nearT, farT;
-                    if (sphereRayIntersect(center, sc.env.radius, dRec.ref, rd, nearT, farT) && !(nearT > 0.f) && !(farT < 0.f)) {
-                        dRec.p = dRec.ref + rd * farT; dRec.n = normalize(center - dRec.p); dRec.measure = 0; dRec.emitter = sc.envEmitter;
-                        dRec.d = rd; dRec.dist = farT;
-                        hitEmitter = true;
-                    }
+                    if (sphereRayIntersect(center, sc.env.radius, dRec.ref, rd, nearT, farT) && !(nearT > 0.f) && !(farT < 0.f)) hitEmitter = true;
+                    /* (a direction the lookup refuses leaves value = 0 and envPdf = 0, as envEval and envPdfDirection do) */
                 }
             } else {                                                                     /* :226-232 */
                 h.id &= ~kHitNotEmitter;
@@ -668,7 +666,7 @@ __global__ void __launch_bounds__(256, 4) kPathBounce(DScene sc, BatchParams bp,
                 }
             }
             if (hitEmitter) {                                                            /* :257-264 */
-                const float lumPdf = rec.w > 0.f ? pdfEmitterDirect(sc, dRec) : 0.f;
+                const float lumPdf = rec.w > 0.f ? (envLooked ? envPdf * (sc.emitters[sc.envEmitter].weight * sc.emitterNormalization) : pdfEmitterDirect(sc, dRec)) : 0.f;
                 const float w = fdiv(bsdfPdf * bsdfPdf, bsdfPdf * bsdfPdf + lumPdf * lumPdf);
                 const f3 c = T * value * w;
                 acc.x += c.x; acc.y += c.y; acc.z += c.z;
@@ -869,22 +867,25 @@ __global__ void __launch_bounds__(256) kResolve(DScene sc, BatchParams bp, WaveB
             if (bp.integrator == KKD_INTEGRATOR_PATH) { const float4 rn = wb.refN[i]; dRec.refN = f3(rn.x, rn.y, rn.z); }
             else dRec.refN = wb.bflags[(size_t)b * bp.stride + i] ? rd : -rd;
             f3 value;
+            float lightPdf;
             if (h.id != kNoHit) {
                 Its bIts; fillIntersection<false>(sc, rd, h, bIts);
                 if (bIts.emitter < 0) continue;
                 value = areaEval(sc.emitters[bIts.emitter], bIts.sh.n, -rd);
                 dRec.p = bIts.p; dRec.n = bIts.sh.n; dRec.d = rd; dRec.dist = h.t; dRec.measure = 0; dRec.emitter = bIts.emitter;
+                lightPdf = rec.w > 0.f ? pdfEmitterDirect(sc, dRec) : 0.f;
             } else {
                 if (sc.envEmitter < 0) continue;
-                value = envEval(sc.env, rd);
+                /* value and density of the environment in this direction share their lookup (pdfEmitterDirect's environment
+                 * branch, scene.cpp:949-952 + envmap.cpp:603-633, written out) */
+                float envPdf;
+                envEvalWithPdf(sc.env, rd, value, envPdf);
                 const f3 center(sc.env.center[0], sc.env.center[1], sc.env.center[2]);   /* envmap.cpp:358-374 */
                 float nearT, farT;
                 if (!sphereRayIntersect(center, sc.env.radius, dRec.ref, rd, nearT, farT) || nearT > 0.f || farT < 0.f) continue;
-                dRec.p = dRec.ref + rd * farT; dRec.n = normalize(center - dRec.p); dRec.measure = 0; dRec.emitter = sc.envEmitter;
-                dRec.d = rd; dRec.dist = farT;
+                lightPdf = rec.w > 0.f ? envPdf * (sc.emitters[sc.envEmitter].weight * sc.emitterNormalization) : 0.f;
             }
             const float bsdfPdf = fabsf(rec.w);
-            const float lightPdf = rec.w > 0.f ? pdfEmitterDirect(sc, dRec) : 0.f;
             const float pa = cB * bsdfPdf, pb = cL * lightPdf;
             const float weight = bp.integrator != KKD_INTEGRATOR_KK ? fdiv(pa * pa, pa * pa + pb * pb) : fdiv(pa, pa + pb);   /* direct.cpp:303-305, path.cpp:263 */
             L += value * f3(rec.x, rec.y, rec.z) * (weight * invNB);

@@ -304,6 +304,21 @@ __device__ __forceinline__ float envPdfDirection(const DEnvMap &e, f3 d) {
     return (luminance(a) * e.rowWeights[min(max(yPos, 0), e.h - 1)] + luminance(b) * e.rowWeights[min(max(yPos + 1, 0), e.h - 1)])
            * e.normalization * frcp(fmaxf(fabsf(sinTheta), kEpsilon));
 }
+/* envEval and envPdfDirection of ONE direction (a BSDF ray that left the scene needs both for its MIS weight): the rotation,
+ * the two inverse trigonometric functions, the four texels and the bilinear rows are computed once; every expression is the
+ * one of the two functions above, so the results are theirs bit for bit */
+__device__ __forceinline__ void envEvalWithPdf(const DEnvMap &e, f3 worldDir, f3 &value, float &pdf) {
+    const f3 v = rot3(e.toLocal, worldDir);
+    const float uu = atan2f(v.x, -v.z) * kInvTwoPi, vv = safeAcos(v.y) * kInvPi;
+    value = f3(0.f); pdf = 0.f;
+    if (!isfinite(uu) || !isfinite(vv)) return;
+    f3 a, b; int yPos;
+    envBilinearRows(e, uu * e.w - 0.5f, vv * e.h - 0.5f, a, b, yPos);
+    value = (a + b) * e.scale;
+    const float sinTheta = safeSqrt(1.f - v.y * v.y);
+    pdf = (luminance(a) * e.rowWeights[min(max(yPos, 0), e.h - 1)] + luminance(b) * e.rowWeights[min(max(yPos + 1, 0), e.h - 1)])
+          * e.normalization * frcp(fmaxf(fabsf(sinTheta), kEpsilon));
+}
 /* envmap.cpp:567-600 */
 __device__ __forceinline__ void envSampleDirection(const DEnvMap &e, f2 sample, f3 &d, f3 &value, float &pdf) {
 #if KKD_ENV_REC_ROWS == 0
