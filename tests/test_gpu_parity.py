@@ -306,6 +306,24 @@ def test_integrator_parameters(gpu, kw):
     _same_seed(gpu, _material_scene(64, 48), 16, tol=2e-6, **kw)
 
 
+@pytest.mark.parametrize("in_flight", [0, 40_000, 1 << 14])
+def test_several_samples_per_kind_in_partial_batches(gpu, in_flight):
+    """The stages hand each other ONE origin per sample and a plane of directions per BSDF / emitter sample (kkd_kernels.h:
+    RaySource).  A batch that fills its buffers traces all planes of a kind in one launch (ray k of plane b -> origin k mod
+    stride); the last, shorter batch traces plane by plane: both against the oracle on the same stream, and against each other."""
+    sc = _material_scene(64, 48)
+    kw = dict(bsdf_samples=3, light_samples=2)
+    o = kkoracle.Oracle(sc)
+    ref, so = o.render(24, seed=1, **kw)
+    with _ctx(gpu, sc, seed=1, max_samples_in_flight=in_flight) as ctx:
+        film, sg = ctx.render(24, **kw)          # 73 728 samples: one batch, 2 batches (the second partial), 5 batches
+    r = helpers.rel_mse(helpers.develop(film), helpers.develop(ref))
+    helpers.record_parity(r, 2e-6)
+    assert sg.samples == so.samples == 64 * 48 * 24
+    assert abs(sg.rays_closest - so.rays_closest) <= 1e-4 * so.rays_closest      # (a BSDF sample that is zero on one side only: a last-bit branch)
+    assert r < 2e-6, r
+
+
 @pytest.mark.parametrize("spp", [1, 3, 5, 100])
 def test_sample_counts_that_do_not_fill_a_wave(gpu, spp):
     film, ref, sg, so = _same_seed(gpu, scenes.cornell_box(50, 38), spp, tol=1e-8)
