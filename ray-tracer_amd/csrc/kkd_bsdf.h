@@ -273,6 +273,52 @@ __device__ __forceinline__ float bsdfPdfBase(const DMaterial &m, const float *rt
         default: return 0.f;
     }
 }
+/* bsdfEvalBase and bsdfPdfBase of ONE pair of directions (the emitter sample's MIS weight needs both, kk/direct.cpp:146-158):
+ * half vector, D, G1(wi) and the plastic's T12 are computed once; every expression is the one of the two functions above, so
+ * value and density are theirs bit for bit */
+__device__ __forceinline__ f3 bsdfEvalPdfBase(const DMaterial &m, const float *rtTables, f3 wi, f3 wo, float &pdf) {
+    pdf = 0.f;
+    switch (m.type) {
+        case KKD_BSDF_DIFFUSE:
+            if (!(m.typeFlags & EDiffuseReflection) || wi.z <= 0.f || wo.z <= 0.f) return f3(0.f);
+            pdf = kInvPi * wo.z;
+            return ld3(m.refl) * (kInvPi * wo.z);
+        case KKD_BSDF_ROUGHCONDUCTOR: {
+            if (wi.z < 0.f || wo.z < 0.f) return f3(0.f);
+            f3 H = normalize(wo + wi);
+            Microfacet distr(m.distr, m.alphaU, m.alphaV, m.sampleVisible != 0);
+            const float D = distr.eval(H), G1i = distr.smithG1(wi, H);
+            if (distr.sampleVisible) pdf = fdiv(D * G1i, 4.0f * wi.z);
+            else pdf = fdiv(D * H.z, 4.f * fabsf(dot(wo, H)));
+            if (D == 0.f) return f3(0.f);
+            f3 F = fresnelConductorExact(dot(wi, H), ld3(m.condEta), ld3(m.condK)) * ld3(m.specRefl);
+            float model = fdiv(D * (G1i * distr.smithG1(wo, H)), 4.0f * wi.z);
+            return F * model;
+        }
+        case KKD_BSDF_ROUGHPLASTIC: {
+            if (wi.z <= 0.f || wo.z <= 0.f) return f3(0.f);
+            const float *tab = rtTables + m.tableOffset;
+            Microfacet distr(m.distr, m.alphaU, m.alphaU, m.sampleVisible != 0);
+            f3 H = normalize(wo + wi);
+            const float D = distr.eval(H), G1i = distr.smithG1(wi, H);
+            const float T12 = roughTransEval(tab, wi.z), T21 = roughTransEval(tab, wo.z);
+            {   /* bsdfPdfBase */
+                const float p = 1.f - T12;
+                const float probSpecular = fdiv(p * m.specSamplingWeight, p * m.specSamplingWeight + (1.f - p) * (1.f - m.specSamplingWeight));
+                const float dpdf = distr.sampleVisible ? fdiv(G1i * fabsf(dot(wi, H)) * D, fabsf(wi.z)) : D * H.z;
+                pdf = dpdf * frcp(4.0f * dot(wo, H)) * probSpecular;
+                pdf += (1.f - probSpecular) * (kInvPi * wo.z);
+            }
+            float value = fdiv(fresnelDielectricExt(dot(wi, H), m.eta) * D * (G1i * distr.smithG1(wo, H)), 4.0f * wi.z);
+            f3 result = ld3(m.specRefl) * value;
+            f3 diff = ld3(m.refl);
+            if (m.nonlinear) diff = diff / (f3(1.0f) - diff * m.fdr); else diff = diff * frcp(1.f - m.fdr);
+            result += diff * (kInvPi * wo.z * T12 * T21 * m.invEta2);
+            return result;
+        }
+        default: return f3(0.f);
+    }
+}
 /* returns the importance weight f*cos/pdf; sampledType gets the BSDF::EBSDFType bit of the lobe */
 __device__ __forceinline__ f3 bsdfSampleBase(const DMaterial &m, const float *rtTables, f3 wi, f2 s, f3 &wo, float &pdfOut, uint32_t &sampledType) {
     sampledType = 0; pdfOut = 0.f; wo = f3(0.f);
@@ -355,6 +401,14 @@ __device__ __forceinline__ float pdfBsdf(const DScene &sc, int id, f3 wi, f3 wo)
         else { wi.z = -wi.z; wo.z = -wo.z; m = sc.materials + m->nested1; }
     }
     return bsdfPdfBase(*m, sc.rtTables, wi, wo);
+}
+__device__ __forceinline__ f3 evalPdfBsdf(const DScene &sc, int id, f3 wi, f3 wo, float &pdf) {
+    const DMaterial *m = sc.materials + id;
+    if (m->type == KKD_BSDF_TWOSIDED) {
+        if (wi.z > 0.f) m = sc.materials + m->nested0;
+        else { wi.z = -wi.z; wo.z = -wo.z; m = sc.materials + m->nested1; }
+    }
+    return bsdfEvalPdfBase(*m, sc.rtTables, wi, wo, pdf);
 }
 __device__ __forceinline__ f3 sampleBsdf(const DScene &sc, int id, f3 wi, f2 s, f3 &wo, float &pdfOut, uint32_t &sampledType) {
     const DMaterial *m = sc.materials + id;

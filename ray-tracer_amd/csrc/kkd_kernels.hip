@@ -588,10 +588,12 @@ __global__ void __launch_bounds__(KKD_SHADE_BLOCK, KKD_SHADE_WAVES * 256 / KKD_S
             } else value = sampleEmitterDirectUnoccluded(sc, dRec, u);
             if (!isZero(value)) {
                 const f3 woLocal = its.sh.toLocal(dRec.d);
-                const f3 bsdfVal = ablation(bp, 32u) ? f3(0.5f) : evalBsdf(sc, its.material, its.wi, woLocal);   /* ($KKD_DEBUG bit 32: no BSDF eval / pdf for the emitter sample) */
+                /* value and density of the BSDF for this pair of directions share their half vector, D, G1 (kkd_bsdf.h: evalPdfBsdf) */
+                float bsdfPdfBoth = 0.5f;
+                const f3 bsdfVal = ablation(bp, 32u) ? f3(0.5f) : evalPdfBsdf(sc, its.material, its.wi, woLocal, bsdfPdfBoth);   /* ($KKD_DEBUG bit 32: no BSDF eval / pdf for the emitter sample) */
                 if (!isZero(bsdfVal) && (!geoTest || dot(its.geoN, dRec.d) * woLocal.z > 0.f)) {   /* :154; direct.cpp:233-234 */
                     const bool onSurface = sc.emitters[dRec.emitter].type != KKD_EMITTER_POINT;
-                    const float bsdfPdf = onSurface ? (ablation(bp, 32u) ? 0.5f : pdfBsdf(sc, its.material, its.wi, woLocal)) : 0.f;
+                    const float bsdfPdf = onSurface ? bsdfPdfBoth : 0.f;
                     const float pa = cL * dRec.pdf, pb = cB * bsdfPdf;
                     const float weight = stock ? fdiv(pa * pa, pa * pa + pb * pb) : fdiv(pa, pb + pa);   /* direct.cpp:241-243, 313-316 */
                     const f3 contrib = value * bsdfVal * (weight * invNL);
@@ -689,10 +691,11 @@ __global__ void __launch_bounds__(256, 4) kPathBounce(DScene sc, BatchParams bp,
                     const f3 lval = sampleEmitterDirectUnoccluded(sc, lRec, u);
                     if (!isZero(lval)) {
                         const f3 woLocal = its.sh.toLocal(lRec.d);
-                        const f3 bsdfVal = evalBsdf(sc, its.material, its.wi, woLocal);
+                        float bsdfPdfBoth;
+                        const f3 bsdfVal = evalPdfBsdf(sc, its.material, its.wi, woLocal, bsdfPdfBoth);   /* value and density from one pass (kkd_bsdf.h) */
                         if (!isZero(bsdfVal) && (!bp.strictNormals || dot(its.geoN, lRec.d) * woLocal.z > 0.f)) {
                             const bool onSurface = sc.emitters[lRec.emitter].type != KKD_EMITTER_POINT;
-                            const float bp2 = onSurface ? pdfBsdf(sc, its.material, its.wi, woLocal) : 0.f;
+                            const float bp2 = onSurface ? bsdfPdfBoth : 0.f;
                             const float w = fdiv(lRec.pdf * lRec.pdf, lRec.pdf * lRec.pdf + bp2 * bp2);
                             const f3 c = T * lval * bsdfVal * w;
                             nl = make_float4(c.x, c.y, c.z, 0.f);
