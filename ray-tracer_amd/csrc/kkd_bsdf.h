@@ -362,9 +362,9 @@ __device__ __forceinline__ f3 bsdfSampleBase(const DMaterial &m, const float *rt
                 sampledType = EDiffuseReflection;
                 wo = squareToCosineHemisphere(s);
             }
-            pdfOut = bsdfPdfBase(m, rtTables, wi, wo);
+            const f3 value = bsdfEvalPdfBase(m, rtTables, wi, wo, pdfOut);      /* roughplastic.cpp: pdf(), then eval() / pdf -- one pass here */
             if (pdfOut == 0.f) return f3(0.f);
-            return bsdfEvalBase(m, rtTables, wi, wo) / pdfOut;
+            return value / pdfOut;
         }
         case KKD_BSDF_DIELECTRIC: {   /* dielectric.cpp:277-308, ERadiance transport */
             float cosThetaT;
