@@ -228,3 +228,38 @@ def test_rough_conductor_under_a_point_light(gpu, distr, alpha, light_dir):
     want = F * D(h[1]) * G1(wv[1]) * G1(wl[1]) / (4 * wv[1]) * I / float(lp @ lp)
     got = _mean_rgb(gpu, sc, 64)
     np.testing.assert_allclose(got, want, rtol=ERROR_REQ)
+
+
+@pytest.mark.parametrize("distr,alpha,nonlinear", [(abi.DISTR_BECKMANN, 0.2, False), (abi.DISTR_GGX, 0.3, True)])
+@pytest.mark.parametrize("light_dir", [(0.5, 1.0, 0.2), (-0.3, 1.0, 0.9)])
+def test_rough_plastic_under_a_point_light(gpu, distr, alpha, nonlinear, light_dir):
+    """roughplastic.cpp:340-380 under one point light, written out from the model, not through the oracle:
+        Lo = [ Ks F(wi.h) D(h) G1(wi) G1(wo) / (4 cos_i)  +  Kd' / pi * cos_o * T12(cos_i) T21(cos_o) / eta^2 ] * I / d^2,
+    Kd' = Kd / (1 - Fdr) or Kd / (1 - Kd Fdr) ('nonlinear'), Fdr = 1 - the diffuse transmittance seen from inside.  F is the
+    textbook dielectric Fresnel term; T12, T21 and Fdr come from the independent numpy integration of the rough dielectric
+    boundary in tests/test_rtrans_protocol.py (the reference's own protocol for that table), so this pins the plastic's eval on the
+    device -- specular lobe, diffuse lobe and the table lookups -- by something that shares no code with product or oracle."""
+    import test_rtrans_protocol as rt
+    int_ior, ext = 1.49, 1.000277
+    eta = float(np.float32(int_ior) / np.float32(ext))
+    Kd = np.array([0.6, 0.3, 0.1]); Ks = 1.0; I = np.array([30.0, 30.0, 30.0])
+    eye = np.array([0.0, 2.0, -2.5])
+    sc = _plane_scene(lambda s: s.roughplastic(tuple(Kd), alpha=alpha, int_ior=int_ior, ext_ior=ext, distribution=distr, nonlinear=nonlinear),
+                      eye=tuple(eye), fov=0.5, size=8)
+    lp = np.array(light_dir, float) * 3.0
+    sc.add_point_light(tuple(lp), I)
+    wv = eye / np.linalg.norm(eye); wl = lp / np.linalg.norm(lp)
+    h = wv + wl; h /= np.linalg.norm(h)
+    D, G1 = _microfacet_d_g1(distr, alpha)
+    F = float(rt.fresnel_dielectric(np.array(float(wv @ h)), eta)[0])
+    spec = Ks * F * D(h[1]) * G1(wv[1]) * G1(wl[1]) / (4 * wv[1])
+    T12 = rt.transmittance(distr, alpha, eta, float(wv[1])); T21 = rt.transmittance(distr, alpha, eta, float(wl[1]))
+    x, w = np.polynomial.legendre.leggauss(24)
+    mu, w = 0.5 * (x + 1), 0.5 * w
+    fdr = 1.0 - float(sum(wk * 2 * m * rt.transmittance(distr, alpha, 1.0 / eta, float(m), 192, 192) for m, wk in zip(mu, w)))
+    kd = Kd / (1 - Kd * fdr) if nonlinear else Kd / (1 - fdr)
+    want = (spec + kd / math.pi * wl[1] * T12 * T21 / (eta * eta)) * I / float(lp @ lp)
+    got = _mean_rgb(gpu, sc, 64)
+    np.testing.assert_allclose(got, want, rtol=ERROR_REQ)
+    if light_dir[2] > 0.5:      # near the mirror direction the specular lobe is a visible part of the answer, off it the diffuse lobe is alone
+        assert spec * I[0] / float(lp @ lp) > 0.02 * want.min()
