@@ -76,3 +76,32 @@ def test_minified_stripes_average_on_the_device(gpu):
         film, _ = ctx.render(4)
     img = helpers.develop(film).reshape(-1, 3)
     np.testing.assert_allclose(img, np.tile([0.7, 0.4, 0.2], (len(img), 1)), rtol=2e-3)
+
+
+@pytest.mark.gpu
+def test_pyramid_levels_are_aligned_with_level_zero(gpu):
+    """closed form, no oracle: a smooth map (three periods around, two from pole to pole) looks the same through the pyramid as
+    through level 0.  At 1024 samples per pixel the ray differentials are pulled in by 1 / sqrt(spp) (integrator.cpp:144-145),
+    the footprint is below a texel, every lookup is the bilinear level-0 value and the pixel filter does the averaging; at ONE
+    sample per pixel a footprint spans ~16 texels and the answer comes from levels 3-5 through the EWA filter (48 such renders
+    with different seeds are averaged, so that the position of the one sample inside its pixel averages out: +-0.03 -> +-0.004).
+    A resampler whose pixel centres were off by half a texel on some level (the classic mistake in (i + 0.5) / target * source)
+    would shift the pattern there by 2^level / 2 texels: at level 4 that is 4 degrees of phase, 0.03 in these units, everywhere
+    the pattern has a slope -- the bound is 0.012."""
+    h, w = 1024, 2048
+    u = (np.arange(w) + 0.5) / w; v = (np.arange(h) + 0.5) / h
+    lum = 1.0 + 0.4 * np.sin(2 * np.pi * 3 * u)[None, :] + 0.3 * np.cos(2 * np.pi * 2 * v)[:, None]
+    tex = np.repeat(lum[..., None], 3, axis=2).astype(np.float32)
+    sc = _env_only_scene(tex, size=32, fov=90.0, target=(0.3, 0.2, -1.0))
+    coarse = 0.0
+    with gpu.Context(device=0, seed=4).upload(sc) as ctx:
+        fine, _ = ctx.render(1024)
+    n = 48
+    for seed in range(n):
+        with gpu.Context(device=0, seed=100 + seed).upload(sc) as ctx:
+            film, _ = ctx.render(1)
+        coarse = coarse + film.astype(np.float64)
+    a, b = helpers.develop(fine)[2:-2, 2:-2, 0], helpers.develop(coarse.astype(np.float32))[2:-2, 2:-2, 0]
+    assert a.std() > 0.1                                    # the pattern is in view
+    d = np.abs(b - a)
+    assert d.max() < 0.012 and d.mean() < 0.004, (d.max(), d.mean())
