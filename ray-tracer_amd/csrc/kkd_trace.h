@@ -99,6 +99,32 @@ __device__ __forceinline__ bool projIntersect(float ox, float oy, float oz, floa
     return true;
 }
 
+#ifdef KKD_TRI_LDS
+/* Experiment of round 3 ("LDS-rotated triangle test"): the ray's origin and direction sit in LDS as (x, y, z, x, y) per lane,
+ * so the components the triangle's axis k selects -- (k, k + 1, k + 2) mod 3 -- are three reads at fixed offsets from one
+ * address instead of twelve selects.  sr = the lane's column (stride BLOCK floats). */
+template <int BLOCK>
+__device__ __forceinline__ bool projIntersectLds(const float *sr, const float4 &r0, const float4 &r1, const float4 &r2,
+                                                 float tmin, float tmax, float &tOut, float &uOut, float &vOut) {
+#pragma clang fp contract(off)
+    const uint32_t k = __float_as_uint(r0.w);
+    if (k > 2u) return false;
+    const float *o = sr + k * BLOCK, *d = sr + (5u + k) * BLOCK;
+    const float o_k = o[0], o_u = o[BLOCK], o_v = o[2 * BLOCK], d_k = d[0], d_u = d[BLOCK], d_v = d[2 * BLOCK];
+    const float n_u = r0.x, n_v = r0.y, n_d = r0.z, a_u = r1.x, a_v = r1.y, b_nu = r1.z, b_nv = r1.w, c_nu = r2.x, c_nv = r2.y;
+    const float num = __fsub_rn(__fsub_rn(__fsub_rn(n_d, __fmul_rn(o_u, n_u)), __fmul_rn(o_v, n_v)), o_k);
+    const float den = __fadd_rn(__fadd_rn(__fmul_rn(d_u, n_u), __fmul_rn(d_v, n_v)), d_k);
+    const float t = __fdiv_rn(num, den);
+    if (t < tmin || t > tmax) return false;
+    const float hu = __fsub_rn(__fadd_rn(o_u, __fmul_rn(t, d_u)), a_u), hv = __fsub_rn(__fadd_rn(o_v, __fmul_rn(t, d_v)), a_v);
+    const float u = __fadd_rn(__fmul_rn(hv, b_nu), __fmul_rn(hu, b_nv));
+    const float v = __fadd_rn(__fmul_rn(hu, c_nu), __fmul_rn(hv, c_nv));
+    if (!(u >= 0.f && v >= 0.f && __fadd_rn(u, v) <= 1.0f)) return false;
+    tOut = t; uOut = u; vOut = v;
+    return true;
+}
+#endif
+
 /* adaptive ray epsilon, skdtree.cpp:126-129 (closest hit) and :213-214 (shadow rays: no inner clamp) */
 template <bool ANY> __device__ __forceinline__ float adaptiveMinT(float mint, float ox, float oy, float oz) {
     if (mint == kEpsilon) {
@@ -166,6 +192,14 @@ struct Walk {
         const uint4 *nodes4 = reinterpret_cast<const uint4 *>(nodes);
         const float4 *tris4 = reinterpret_cast<const float4 *>(tris);
         const int tid = threadIdx.x;
+#ifdef KKD_TRI_LDS
+        __shared__ float sray[10 * BLOCK];
+        if (PROJ) {   /* only this lane reads its column: no barrier */
+            float *sr = sray + tid;
+            sr[0] = ox; sr[BLOCK] = oy; sr[2 * BLOCK] = oz; sr[3 * BLOCK] = ox; sr[4 * BLOCK] = oy;
+            sr[5 * BLOCK] = dx; sr[6 * BLOCK] = dy; sr[7 * BLOCK] = dz; sr[8 * BLOCK] = dx; sr[9 * BLOCK] = dy;
+        }
+#endif
 #define KKD_PUSH(V) { if (sp < STACK) sstack[sp * BLOCK + tid] = (V); else ovf[sp - STACK] = (V); ++sp; }
 /* the LDS read is unconditional and the private read a separate, rarely taken branch: one select between the two
  * pointers would turn every pop into a flat load, which goes the long way round through the texture addresser */
@@ -290,7 +324,11 @@ struct Walk {
                      * into tiles or sample ranges groups the rays differently (coplanar emitters made 4 pixels of C3 differ), and
                      * slot numbers depend on which builder made the tree */
                     const uint32_t prim = PROJ ? __float_as_uint(c.z) : __float_as_uint(a.w);
+#if defined(KKD_TRI_LDS) && KKD_TRI_LDS != 2     /* (2: the LDS is taken and written, the test reads registers -- what the occupancy alone costs) */
+                    if ((PROJ ? projIntersectLds<BLOCK>(sray + tid, a, b, c, tmin, tmax, t, u, v)
+#else
                     if ((PROJ ? projIntersect(ox, oy, oz, dx, dy, dz, a, b, c, tmin, tmax, t, u, v)
+#endif
                               : woopIntersect(wr, ox, oy, oz, a, b, c, tmin, tmax, t, u, v))
                         && (ANY || t < tmax || hit.id == kNoHit || prim < hprim)) {
                         tmax = t; hit.t = t; hit.u = u; hit.v = v; hit.id = slot; hprim = prim;
