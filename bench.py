@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="camera samples in flight per batch (0 = library default)")
     args = ap.parse_args()
 
+    # the host driver of this pool only supports dmabuf IPC: without this RCCL's peer setup fails with "hipIpcGetMemHandle: invalid
+    # argument" (the launcher's environment normally carries it already)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
