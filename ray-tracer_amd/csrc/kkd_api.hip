@@ -651,6 +651,8 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
     for (int attempt = 0;; ++attempt) {
         batch = std::max<uint64_t>(256, (batchCap + 255) / 256 * 256);
         batch = std::min<uint64_t>(batch, 1ull << 28);
+        /* the rays of one kind of a batch are traced by one launch and numbered with 32 bits (continuation records, RaySource) */
+        batch = std::min<uint64_t>(batch, std::max<uint64_t>(256, ((1ull << 31) / std::max<uint64_t>(1, std::max(nB, nL))) / 256 * 256));
         batch = std::min<uint64_t>(batch, std::max<uint64_t>(256, (total + 255) / 256 * 256));
         if ((!ctx->cfg.max_samples_in_flight || attempt > 0) && envLanes >= 2 && total >= (1ull << 21)) {
             /* library default: an even number of equal batches, so both batch lanes work to the end */
