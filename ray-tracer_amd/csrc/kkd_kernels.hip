@@ -1070,7 +1070,9 @@ static void launchPhasedT(hipStream_t st, const DScene &sc, const RaySource &ray
     /* rounds: [0, cap) on all rays, then (rounds > 2 only) cap more steps on what is left, ...; the last round walks to the end
      * as persistent waves that draw the parked rays themselves (kTraceTail).  With more than two rounds the two halves of the
      * continuation buffer alternate as input and output; with two the first round parks into the whole buffer. */
-    static const int tailBlocks = [] { const char *e = getenv("KKD_TAIL_PERSIST"); return e ? atoi(e) : 1; }();   /* blocks per shard; 0: developer switch, plain resume kernel */
+    static const int tailBlocksAll = [] { const char *e = getenv("KKD_TAIL_PERSIST"); return e ? atoi(e) : 1; }();   /* blocks per shard; 0: developer switch, plain resume kernel */
+    static const int tailBlocksAny = [] { const char *e = getenv("KKD_TAIL_PERSIST_ANY"); return e ? atoi(e) : -1; }();   /* the same for shadow rays only (A/B runs) */
+    const int tailBlocks = (ANY && tailBlocksAny >= 0) ? tailBlocksAny : tailBlocksAll;
     const int rounds = cont.rounds < 2 ? 2 : cont.rounds;
     TraceContinuation bufs[2] = { cont, cont };
     if (rounds > 2) {
