@@ -85,8 +85,9 @@ def stage_bytes(st, n_b, n_l, per_ray, node_bytes=64.0, tri_bytes=48.0):
     io = (16.0, 48.0, 36.0)   # primary: hit write; bsdf: ray read + hit write; shadow: ray read + flag write
     trav = [rays[k] * (io[k] + per_ray[k][0] * node_bytes + per_ray[k][1] * tri_bytes) for k in range(3)]
     s = float(st.samples)
-    shade = s * (16 + tri_bytes + 12 + 36 + 32 + 128 + 64 + 12 + 36 + 16 + 16 + n_b * 48 + n_l * 48)
-    resolve = s * (16 + 16 + n_b * 64 + n_l * 20 + 125.0 / 64.0 * 8.0)
+    # round 3 record layout: one origin per sample, direction planes, flag bytes; accum only where it is not the default
+    shade = s * (16 + tri_bytes + 12 + 36 + 32 + 128 + 64 + 12 + 36 + 16 + 1 + n_b * (16 + 16 + 1) + n_l * (16 + 16))
+    resolve = s * (1 + 16 + n_b * (16 + 16 + 16 + 1) + n_l * 20 + 125.0 / 64.0 * 8.0)
     return [trav[0], shade, trav[1], trav[2], resolve]
 
 
