@@ -168,6 +168,12 @@ template <int OUT> __device__ __forceinline__ void storeTraceResult(void *__rest
 #ifndef KKD_FIRST_BLOCK
 #define KKD_FIRST_BLOCK 256    /* workgroup of the first traversal round: the rays that are sorted together */
 #endif
+#ifndef KKD_REPACK_AT
+#define KKD_REPACK_AT 0        /* experiment: steps of the first round after which a workgroup moves its walking rays together (0 = never) */
+#endif
+#ifndef KKD_REPACK_WORDS
+#define KKD_REPACK_WORDS 4
+#endif
 #ifndef KKD_SORT_ANY
 #define KKD_SORT_ANY 1         /* the same for shadow rays (0: only their dead rays are squeezed out, the layout of round 2) */
 #endif
@@ -353,8 +359,56 @@ __global__ void __launch_bounds__(BLOCK, 8) kTraceRound(const Node4 *__restrict_
         }
     }
     bool parked = false;
+    int budget = next.iterCap;
+#if KKD_REPACK_AT > 0
+    /* Experiment: after KKD_REPACK_AT steps the rays of the workgroup that are still walking are moved together into its first
+     * waves (the others have their result stored and their waves leave), so that the rest of the round does not issue for
+     * lanes that are done.  A ray keeps its column of the LDS stack (Walk::col): only nine words of state travel, through a
+     * 4 KB buffer in three passes; the ray itself is read again. */
+    constexpr int RPW = KKD_REPACK_WORDS;            /* words per lane and pass of the exchange buffer */
+    __shared__ uint32_t sx[RPW * BLOCK];
+    if (FIRST && next.iterCap > KKD_REPACK_AT) {
+        w.run(nodes, triTable, sstack, ovf, nn, nt, KKD_REPACK_AT);
+        budget -= KKD_REPACK_AT;
+        const bool live = mine && !w.finished();
+        /* a stack that has spilled into the lane's private array cannot travel: such a workgroup (rare) walks on as it is */
+        if (!__syncthreads_or(live && w.sp > STACK)) {
+        if (mine && !live) { storeTraceResult<OUT>(out, r.ray, w.hit, tris); mine = false; }
+        const unsigned long long lm = __ballot(live);
+        const uint32_t wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63u) == 0u) sx[wave] = (uint32_t)__popcll(lm);
+        __syncthreads();
+        uint32_t base = 0, total = 0;
+#pragma unroll
+        for (uint32_t wv = 0; wv < BLOCK / 64; ++wv) { const uint32_t c = sx[wv]; if (wv < wave) base += c; total += c; }
+        __syncthreads();
+        if (total == 0u) {                                       /* block-uniform: every ray of the workgroup is done */
+            if (ctr) { ctr = counterShard(ctr); if (FIRST) countRays(traced, &ctr->rays[cls]); if (COUNT) countTraversal(nn, nt, ctr, cls); }
+            return;
+        }
+        const uint32_t dst = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+        const bool take = threadIdx.x < total;
+        uint32_t g[10] = { r.ray, w.cur, w.pend, (uint32_t)w.sp, __float_as_uint(w.tmax), __float_as_uint(w.hit.u), __float_as_uint(w.hit.v), w.hit.id, w.hprim, (uint32_t)w.col };
+#pragma unroll
+        for (int pass = 0; pass < (10 + RPW - 1) / RPW; ++pass) {
+            if (live) { for (int j = 0; j < RPW; ++j) if (RPW * pass + j < 10) sx[j * BLOCK + dst] = g[RPW * pass + j]; }
+            __syncthreads();
+            if (take) { for (int j = 0; j < RPW; ++j) if (RPW * pass + j < 10) g[RPW * pass + j] = sx[j * BLOCK + threadIdx.x]; }
+            __syncthreads();
+        }
+        mine = take;
+        if (mine) {
+            r.ray = g[0];
+            ray = loadRay<SHARE>(rays, dirs, stride, r.ray);
+            w.begin(ray);
+            w.resume(g[1], g[2], (int)g[3], __uint_as_float(g[4]), __uint_as_float(g[5]), __uint_as_float(g[6]), g[7], g[8]);
+            w.col = (int)g[9];
+        } else w.stop();
+        }
+    }
+#endif
     if (next.iterCap > 0) {
-        w.run(nodes, triTable, sstack, ovf, nn, nt, next.iterCap);
+        w.run(nodes, triTable, sstack, ovf, nn, nt, budget);
         const bool unfinished = !w.finished();
         if (__ballot(unfinished) != 0ull) {
             const bool want = unfinished && w.sp <= STACK;      /* a stack that has spilled into private memory stays here */
@@ -382,8 +436,8 @@ __global__ void __launch_bounds__(BLOCK, 8) kTraceRound(const Node4 *__restrict_
                 next.recs[slot] = o;
 #pragma unroll
                 for (int q = 0; q < STACK / 4; ++q)
-                    next.stacks[slot * (STACK / 4) + q] = make_uint4(sstack[(4 * q) * BLOCK + threadIdx.x], sstack[(4 * q + 1) * BLOCK + threadIdx.x],
-                                                                     sstack[(4 * q + 2) * BLOCK + threadIdx.x], sstack[(4 * q + 3) * BLOCK + threadIdx.x]);
+                    next.stacks[slot * (STACK / 4) + q] = make_uint4(sstack[(4 * q) * BLOCK + w.col], sstack[(4 * q + 1) * BLOCK + w.col],
+                                                                     sstack[(4 * q + 2) * BLOCK + w.col], sstack[(4 * q + 3) * BLOCK + w.col]);
                 w.stop();
             }
         }

@@ -161,6 +161,7 @@ struct Walk {
      * object in scratch memory) */
     DHit hit; uint32_t hprim;                        /* hprim: primitive id of the best hit (equal-distance ties) */
     float ox, oy, oz, dx, dy, dz, tmin, tmax, idx, idy, idz; WoopRay wr; uint32_t cur, pend; int sp;
+    int col;                                         /* the lane's column of the LDS stack: its thread index, unless the ray was moved to another lane (KKD_REPACK_AT) */
 
     __device__ __forceinline__ void begin(const DRay &ray) {
         hit.t = kInf; hit.u = 0.f; hit.v = 0.f; hit.id = kNoHit; hprim = 0u;
@@ -174,7 +175,7 @@ struct Walk {
         idy = fabsf(dy) < kTiny ? copysignf(kBig, dy) : 1.0f / dy;
         idz = fabsf(dz) < kTiny ? copysignf(kBig, dz) : 1.0f / dz;
         if (!PROJ) wr.init(dx, dy, dz);
-        sp = 0; pend = 0u;
+        sp = 0; pend = 0u; col = (int)threadIdx.x;
         cur = (tmax > tmin) ? 0u : kTraversalDone;      /* cur: inner node index | leaf reference (kLeafBit) | kTraversalDone */
     }
     /* pend: the leaf whose triangles are still to be tested (a leaf reference, 0 = none) */
@@ -191,7 +192,7 @@ struct Walk {
         const bool negx = idx < 0.f, negy = idy < 0.f, negz = idz < 0.f;
         const uint4 *nodes4 = reinterpret_cast<const uint4 *>(nodes);
         const float4 *tris4 = reinterpret_cast<const float4 *>(tris);
-        const int tid = threadIdx.x;
+        const int tid = col;
 #ifdef KKD_TRI_LDS
         __shared__ float sray[10 * BLOCK];
         if (PROJ) {   /* only this lane reads its column: no barrier */
