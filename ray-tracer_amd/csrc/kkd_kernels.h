@@ -7,7 +7,7 @@ namespace kkd {
 
 /* per ray class (KKD_RAYS_PRIMARY / _BSDF / _SHADOW) */
 /* traversal stack capacity per lane: kStackLds entries in LDS + kStackOverflow in private memory (kkd_trace.h) */
-static constexpr int kMaxTraversalStack = 16 + 80;
+static constexpr int kMaxTraversalStack = 12 + 80;   /* the shallower of the two walks: shadow rays keep 12 entries in LDS (kkd_trace.h), the others 16 */
 
 /* One word takes only ~88 M atomic adds per second, far fewer than the waves a render retires, so the counters are
  * sharded: a wave adds into shard (blockIdx.x % kCounterShards), each shard on its own 128-byte line; the host sums. */

@@ -240,7 +240,8 @@ __device__ __forceinline__ void storeTraceResult(void *__restrict__ out, uint64_
     }
 }
 
-static_assert(kStackLds == 16, "TraceContinuation stores 16 stack words per parked ray");
+static_assert(kStackLds % 4 == 0 && kStackLds >= 4 && kStackLds <= 16, "TraceContinuation stores up to 16 stack words per parked ray, as uint4s");
+static_assert(kStackLdsAny % 4 == 0 && kStackLdsAny >= 4 && kStackLdsAny <= 16, "TraceContinuation stores up to 16 stack words per parked ray, as uint4s");
 
 /* One round.  FIRST: lanes take rays [0, n) of the ray buffer; else lanes take the records parked in `in` by the round
  * before.  next.iterCap > 0: stop after that many steps and park what is still walking in `next`; else walk to the end. */
@@ -1102,7 +1103,7 @@ void launchPrimary(hipStream_t st, bool count, const DScene &sc, const BatchPara
 template <bool ANY, bool COUNT, int OUT>
 static void launchTraceT(hipStream_t st, const DScene &sc, const RaySource &rays, uint64_t n, void *out, DeviceCounters *ctr, int cls) {
     constexpr bool canShare = (ANY && OUT == 2) || (!ANY && OUT == 0);       /* only the render path's rays come without origins */
-#define KKD_LT(P, S) hipLaunchKernelGGL((kTrace<ANY, COUNT, OUT, P, kStackLds, 256, S>), dim3(blocksFor(n, 256)), dim3(256), 0, st, sc.nodes, sc.tris, sc.projTris, rays.rays, rays.dirs, rays.stride, n, out, ctr, cls)
+#define KKD_LT(P, S) hipLaunchKernelGGL((kTrace<ANY, COUNT, OUT, P, (ANY ? kStackLdsAny : kStackLds), 256, S>), dim3(blocksFor(n, 256)), dim3(256), 0, st, sc.nodes, sc.tris, sc.projTris, rays.rays, rays.dirs, rays.stride, n, out, ctr, cls)
     if (canShare && rays.dirs) { if (sc.projTris) KKD_LT(true, canShare); else KKD_LT(false, canShare); }
     else { if (sc.projTris) KKD_LT(true, false); else KKD_LT(false, false); }
 #undef KKD_LT
@@ -1132,7 +1133,7 @@ static void launchPhasedT(hipStream_t st, const DScene &sc, const RaySource &ray
     if (rounds > 2) {
         const uint32_t half = cont.perShard / 2;
         bufs[0].perShard = bufs[1].perShard = half;
-        bufs[1].recs = cont.recs + (size_t)kContShards * half; bufs[1].stacks = cont.stacks + (size_t)kContShards * half * (kStackLds / 4);
+        bufs[1].recs = cont.recs + (size_t)kContShards * half; bufs[1].stacks = cont.stacks + (size_t)kContShards * half * ((ANY ? kStackLdsAny : kStackLds) / 4);
     }
     bufs[1].count = cont.count + kContShards * 32;
     hipMemsetAsync(cont.count, 0, 2 * kContShards * 32 * sizeof(uint32_t), st);   /* both counter arrays of this ray kind (fill counters and kTraceTail's consume counters) */
@@ -1143,12 +1144,12 @@ static void launchPhasedT(hipStream_t st, const DScene &sc, const RaySource &ray
         TraceContinuation in = bufs[(r + 1) & 1], next = bufs[r & 1];
         next.iterCap = (r + 1 < rounds) ? (r == 0 ? cont.iterCap : cont.iterCapLater) : 0;
         if (r >= 2 && next.iterCap > 0) hipMemsetAsync(next.count, 0, kContShards * 32 * sizeof(uint32_t), st);
-        if (r == 0) hipLaunchKernelGGL((kTraceRound<ANY, COUNT, OUT, PROJ, true, kStackLds, KKD_FIRST_BLOCK, SHARE>), dim3(blocksFor(n, KKD_FIRST_BLOCK)), dim3(KKD_FIRST_BLOCK), 0, st,
+        if (r == 0) hipLaunchKernelGGL((kTraceRound<ANY, COUNT, OUT, PROJ, true, (ANY ? kStackLdsAny : kStackLds), KKD_FIRST_BLOCK, SHARE>), dim3(blocksFor(n, KKD_FIRST_BLOCK)), dim3(KKD_FIRST_BLOCK), 0, st,
                                        sc.nodes, sc.tris, sc.projTris, rays.rays, rays.dirs, rays.stride, n, out, ctr, cls, in, next);
         else if (next.iterCap == 0 && tailBlocks > 0)
-            hipLaunchKernelGGL((kTraceTail<ANY, COUNT, OUT, PROJ, kStackLds, 256, SHARE>), dim3(kContShards * (uint32_t)std::min(tailBlocks, 8)), block, 0, st,
+            hipLaunchKernelGGL((kTraceTail<ANY, COUNT, OUT, PROJ, (ANY ? kStackLdsAny : kStackLds), 256, SHARE>), dim3(kContShards * (uint32_t)std::min(tailBlocks, 8)), block, 0, st,
                                sc.nodes, sc.tris, sc.projTris, rays.rays, rays.dirs, rays.stride, out, ctr, cls, in);
-        else hipLaunchKernelGGL((kTraceRound<ANY, COUNT, OUT, PROJ, false, kStackLds, 256, SHARE>), resumeGrid, block, 0, st,
+        else hipLaunchKernelGGL((kTraceRound<ANY, COUNT, OUT, PROJ, false, (ANY ? kStackLdsAny : kStackLds), 256, SHARE>), resumeGrid, block, 0, st,
                                 sc.nodes, sc.tris, sc.projTris, rays.rays, rays.dirs, rays.stride, n, out, ctr, cls, in, next);
     }
 }

@@ -17,7 +17,17 @@
 
 namespace kkd {
 
-static constexpr int kStackLds = 16;        /* LDS-resident stack entries per lane           */
+#ifndef KKD_STACK_LDS
+#define KKD_STACK_LDS 16      /* a multiple of 4 up to 16 (parked rays carry these words: TraceContinuation holds 16 per record) */
+#endif
+static constexpr int kStackLds = KKD_STACK_LDS;   /* LDS-resident stack entries per lane           */
+/* Shadow rays stop at their first hit and seldom stack deep; every KB of LDS a workgroup does not take shows in the two-lane
+ * job (profiles/r3_ab_lds_stack.txt: 12 entries: C4 shadow stage 306 -> 301 ms, C2 29.1 -> 27.7 ms; 8 entries: C4 334 ms, the private
+ * part gets used; 12 for ALL walks: BSDF stage 433 -> 440 ms) */
+#ifndef KKD_STACK_LDS_ANY
+#define KKD_STACK_LDS_ANY 12
+#endif
+static constexpr int kStackLdsAny = KKD_STACK_LDS_ANY;   /* the same for the occlusion walk of the render path and of kkd_trace* */
 static constexpr int kStackOverflow = 80;   /* further entries in private (scratch) memory   */
 
 __device__ __forceinline__ float selc(float x, float y, float z, int k) { return k == 0 ? x : (k == 1 ? y : z); }
