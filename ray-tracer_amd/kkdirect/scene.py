@@ -156,6 +156,27 @@ class Scene:
         self._check_smooth(face_normals, max_smooth_angle)
         return self.add_loaded_mesh(load_ply(path, to_world, srgb, max_smooth_angle), material, face_normals, flip_normals, **kw)
 
+    def add_obj(self, path, material, shape_index=-1, to_world=None, collapse=False, flip_tex_coords=True, face_normals=None,
+                flip_normals=False, max_smooth_angle=None, **kw):
+        """<shape type="obj"> (reference src/shapes/obj.cpp:189-349): one shape per mesh the plugin creates for `shapeIndex` (its
+        rule, quirk included: kkdirect.obj_shape_index_meshes).  material: one material id for every mesh (an unnamed <bsdf>
+        child), or a dict usemtl-name -> id with "" as the fallback, which is how WavefrontOBJ::addChild hands named BSDFs to
+        the meshes (obj.cpp:738-757).  Returns the shape ids."""
+        from . import load_obj, obj_mesh_count, obj_shape_index_meshes
+        self._check_smooth(face_normals, max_smooth_angle)
+        count, eof = obj_mesh_count(path, collapse)
+        ids = []
+        for k in obj_shape_index_meshes(count, eof, shape_index):
+            m = load_obj(path, k, to_world, collapse, flip_tex_coords, max_smooth_angle)
+            if isinstance(material, dict):
+                if m["material"] not in material and "" not in material:
+                    raise ValueError("no material for the OBJ material name %r" % m["material"])
+                mat = material.get(m["material"], material.get(""))
+            else:
+                mat = material
+            ids.append(self.add_loaded_mesh(m, mat, face_normals, flip_normals, **kw))
+        return ids
+
     def add_point_light(self, position, intensity, sampling_weight=1.0):
         e = abi.Emitter()
         e.type = abi.EMITTER_POINT; e.shape_id = -1; e.sampling_weight = sampling_weight

@@ -237,6 +237,76 @@ def test_render_scene_loaded_from_files(gpu, tmp_path):
     assert f1[..., 4].sum() > 0 and np.allclose(f1, f2, rtol=1e-4, atol=1e-4)
 
 
+def _write_obj(path, meshes):
+    """positions / texcoords / normals per corner index, one "g" + "usemtl" per mesh"""
+    nv = 0
+    with open(path, "w") as f:
+        for m in meshes:
+            for q in m["positions"]:
+                f.write("v %.9g %.9g %.9g\n" % tuple(q))
+            if m["texcoords"] is not None:
+                for q in m["texcoords"]:
+                    f.write("vt %.9g %.9g\n" % (q[0], 1.0 - q[1]))
+            if m["normals"] is not None:
+                for q in m["normals"]:
+                    f.write("vn %.9g %.9g %.9g\n" % tuple(q))
+        nt = nn = 0
+        for m in meshes:
+            f.write("g %s\nusemtl %s\n" % (m["name"], m["name"] + "_mat"))
+            for t in m["indices"]:
+                def corner(i):
+                    a = str(nv + i + 1)
+                    tt = str(nt + i + 1) if m["texcoords"] is not None else ""
+                    nn_ = str(nn + i + 1) if m["normals"] is not None else ""
+                    return a if not (tt or nn_) else (a + "/" + tt if not nn_ else a + "/" + tt + "/" + nn_)
+                f.write("f %s %s %s\n" % tuple(corner(int(i)) for i in t))
+            nv += len(m["positions"])
+            nt += len(m["texcoords"]) if m["texcoords"] is not None else 0
+            nn += len(m["normals"]) if m["normals"] is not None else 0
+
+
+def test_scene_from_obj_equals_scene_from_arrays(tmp_path):
+    """two groups with their own materials: the shapes, their order, their materials and their arrays are what add_mesh gives
+    for the same data (vertices come out in first-use order, so the comparison is per triangle corner)"""
+    a = _mesh(21, n=7, normals=False, uv=False, name="floor")
+    b = _mesh(22, n=5, normals=True, uv=True, name="wall")
+    _write_obj(str(tmp_path / "two.obj"), [a, b])
+    s1 = Scene(); ma, mb = s1.diffuse((0.2, 0.3, 0.4)), s1.diffuse((0.7, 0.6, 0.5))
+    ids = s1.add_obj(str(tmp_path / "two.obj"), {"floor_mat": ma, "wall_mat": mb})
+    assert len(ids) == 2
+    assert [kkdirect.load_obj(str(tmp_path / "two.obj"), k)["material"] for k in range(2)] == ["floor_mat", "wall_mat"]
+    lm = [kkdirect.load_obj(str(tmp_path / "two.obj"), k) for k in range(2)]
+    for got, want in zip(lm, (a, b)):
+        assert np.array_equal(got["positions"][got["indices"]], want["positions"][want["indices"]])
+        if want["texcoords"] is not None:
+            np.testing.assert_allclose(got["texcoords"][got["indices"]], want["texcoords"][want["indices"]], atol=1e-7)
+            np.testing.assert_allclose(got["normals"][got["indices"]], want["normals"][want["indices"]], atol=2e-7)
+    assert s1.add_obj(str(tmp_path / "two.obj"), ma, shape_index=0) and len(s1.add_obj(str(tmp_path / "two.obj"), ma, shape_index=0)) == 2   # obj.cpp:332: the last mesh comes with number count - 2
+    with pytest.raises(ValueError, match="no material"):
+        Scene().add_obj(str(tmp_path / "two.obj"), {"floor_mat": 0})
+
+
+@pytest.mark.gpu
+def test_render_scene_loaded_from_obj(gpu, tmp_path):
+    ground = _mesh(15, n=20, normals=False, uv=False, name="ground")
+    ground["positions"] = (ground["positions"] * np.float32(120) + np.float32([278, 60, 280])).astype(np.float32)
+    _write_obj(str(tmp_path / "g.obj"), [ground])
+
+    def build(from_file):
+        sc = scenes.cornell_box(64, 64)
+        m = sc.diffuse((0.3, 0.5, 0.7))
+        if from_file:
+            sc.add_obj(str(tmp_path / "g.obj"), m)
+        else:
+            sc.add_mesh(ground["positions"], ground["indices"], m, normals=kkdirect.compute_vertex_normals(ground["positions"], ground["indices"]))
+        return sc
+    with gpu.Context(device=0).upload(build(True)) as c1, gpu.Context(device=0).upload(build(False)) as c2:
+        f1, _ = c1.render(8)
+        f2, _ = c2.render(8)
+    # same triangles in the same order (the OBJ reader numbers vertices by first use: generated normals agree to rounding)
+    assert f1[..., 4].sum() > 0 and np.allclose(f1, f2, rtol=2e-3, atol=2e-3)
+
+
 # ---- maxSmoothAngle: TriMesh::rebuildTopology (reference src/librender/trimesh.cpp:472-610) ---------------------------------
 def _cube_mesh(shared=True):
     """a unit cube: 8 shared vertices / 12 triangles, or the same triangles with one private vertex per corner"""
