@@ -240,8 +240,25 @@ __device__ __forceinline__ void storeTraceResult(void *__restrict__ out, uint64_
     }
 }
 
-static_assert(kStackLds % 4 == 0 && kStackLds >= 4 && kStackLds <= 16, "TraceContinuation stores up to 16 stack words per parked ray, as uint4s");
-static_assert(kStackLdsAny % 4 == 0 && kStackLdsAny >= 4 && kStackLdsAny <= 16, "TraceContinuation stores up to 16 stack words per parked ray, as uint4s");
+/* the LDS part of a parked ray's stack travels as (STACK + 3) / 4 uint4s; entries past STACK do not exist */
+template <int STACK, int BLOCK> __device__ __forceinline__ void stackToLds(uint32_t *sstack, int col, const uint4 *src) {
+#pragma unroll
+    for (int q = 0; q < (STACK + 3) / 4; ++q) {
+        const uint4 s4 = src[q];
+        sstack[(4 * q) * BLOCK + col] = s4.x;
+        if (4 * q + 1 < STACK) sstack[(4 * q + 1) * BLOCK + col] = s4.y;
+        if (4 * q + 2 < STACK) sstack[(4 * q + 2) * BLOCK + col] = s4.z;
+        if (4 * q + 3 < STACK) sstack[(4 * q + 3) * BLOCK + col] = s4.w;
+    }
+}
+template <int STACK, int BLOCK> __device__ __forceinline__ void stackFromLds(const uint32_t *sstack, int col, uint4 *dst) {
+#pragma unroll
+    for (int q = 0; q < (STACK + 3) / 4; ++q)
+        dst[q] = make_uint4(sstack[(4 * q) * BLOCK + col], 4 * q + 1 < STACK ? sstack[(4 * q + 1) * BLOCK + col] : 0u,
+                            4 * q + 2 < STACK ? sstack[(4 * q + 2) * BLOCK + col] : 0u, 4 * q + 3 < STACK ? sstack[(4 * q + 3) * BLOCK + col] : 0u);
+}
+static_assert(kStackLds >= 4 && kStackLds <= 16, "TraceContinuation stores up to 16 stack words per parked ray");
+static_assert(kStackLdsAny >= 4 && kStackLdsAny <= 16, "TraceContinuation stores up to 16 stack words per parked ray");
 
 /* One round.  FIRST: lanes take rays [0, n) of the ray buffer; else lanes take the records parked in `in` by the round
  * before.  next.iterCap > 0: stop after that many steps and park what is still walking in `next`; else walk to the end. */
@@ -351,12 +368,7 @@ __global__ void __launch_bounds__(BLOCK, 8) kTraceRound(const Node4 *__restrict_
     if (!FIRST) {
         w.resume(r.cur, r.pend, (int)r.sp, r.tmax, r.u, r.v, r.id, (mine && r.id != kNoHit) ? tris[r.id].prim : 0u);
         if (mine) {
-#pragma unroll
-            for (int q = 0; q < STACK / 4; ++q) {
-                const uint4 s4 = in.stacks[inSlot * (STACK / 4) + q];
-                sstack[(4 * q) * BLOCK + threadIdx.x] = s4.x; sstack[(4 * q + 1) * BLOCK + threadIdx.x] = s4.y;
-                sstack[(4 * q + 2) * BLOCK + threadIdx.x] = s4.z; sstack[(4 * q + 3) * BLOCK + threadIdx.x] = s4.w;
-            }
+            stackToLds<STACK, BLOCK>(sstack, (int)threadIdx.x, in.stacks + inSlot * ((STACK + 3) / 4));
         }
     }
     bool parked = false;
@@ -435,10 +447,7 @@ __global__ void __launch_bounds__(BLOCK, 8) kTraceRound(const Node4 *__restrict_
             if (parked) {
                 ContRec o; o.ray = r.ray; o.cur = w.cur; o.sp = (uint32_t)w.sp; o.tmax = w.tmax; o.pend = w.pend; o.u = w.hit.u; o.v = w.hit.v; o.id = w.hit.id;
                 next.recs[slot] = o;
-#pragma unroll
-                for (int q = 0; q < STACK / 4; ++q)
-                    next.stacks[slot * (STACK / 4) + q] = make_uint4(sstack[(4 * q) * BLOCK + w.col], sstack[(4 * q + 1) * BLOCK + w.col],
-                                                                     sstack[(4 * q + 2) * BLOCK + w.col], sstack[(4 * q + 3) * BLOCK + w.col]);
+                stackFromLds<STACK, BLOCK>(sstack, w.col, next.stacks + slot * ((STACK + 3) / 4));
                 w.stop();
             }
         }
@@ -496,12 +505,7 @@ __global__ void __launch_bounds__(BLOCK, 8) kTraceTail(const Node4 *__restrict__
                     ray = loadRay<SHARE>(rays, dirs, stride, r.ray); myRay = r.ray; have = true;
                     w.begin(ray);
                     w.resume(r.cur, r.pend, (int)r.sp, r.tmax, r.u, r.v, r.id, r.id != kNoHit ? tris[r.id].prim : 0u);
-#pragma unroll
-                    for (int q = 0; q < STACK / 4; ++q) {
-                        const uint4 s4 = in.stacks[slot * (STACK / 4) + q];
-                        sstack[(4 * q) * BLOCK + threadIdx.x] = s4.x; sstack[(4 * q + 1) * BLOCK + threadIdx.x] = s4.y;
-                        sstack[(4 * q + 2) * BLOCK + threadIdx.x] = s4.z; sstack[(4 * q + 3) * BLOCK + threadIdx.x] = s4.w;
-                    }
+                    stackToLds<STACK, BLOCK>(sstack, (int)threadIdx.x, in.stacks + slot * ((STACK + 3) / 4));
                 }
             }
         }
@@ -1133,7 +1137,7 @@ static void launchPhasedT(hipStream_t st, const DScene &sc, const RaySource &ray
     if (rounds > 2) {
         const uint32_t half = cont.perShard / 2;
         bufs[0].perShard = bufs[1].perShard = half;
-        bufs[1].recs = cont.recs + (size_t)kContShards * half; bufs[1].stacks = cont.stacks + (size_t)kContShards * half * ((ANY ? kStackLdsAny : kStackLds) / 4);
+        bufs[1].recs = cont.recs + (size_t)kContShards * half; bufs[1].stacks = cont.stacks + (size_t)kContShards * half * (((ANY ? kStackLdsAny : kStackLds) + 3) / 4);
     }
     bufs[1].count = cont.count + kContShards * 32;
     hipMemsetAsync(cont.count, 0, 2 * kContShards * 32 * sizeof(uint32_t), st);   /* both counter arrays of this ray kind (fill counters and kTraceTail's consume counters) */

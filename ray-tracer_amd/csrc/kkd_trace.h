@@ -18,7 +18,7 @@
 namespace kkd {
 
 #ifndef KKD_STACK_LDS
-#define KKD_STACK_LDS 16      /* a multiple of 4 up to 16 (parked rays carry these words: TraceContinuation holds 16 per record) */
+#define KKD_STACK_LDS 16      /* 4 ... 16 (parked rays carry these words: TraceContinuation holds 16 per record) */
 #endif
 static constexpr int kStackLds = KKD_STACK_LDS;   /* LDS-resident stack entries per lane           */
 /* Shadow rays stop at their first hit and seldom stack deep; every KB of LDS a workgroup does not take shows in the two-lane
