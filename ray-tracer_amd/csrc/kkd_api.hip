@@ -641,11 +641,11 @@ static int renderImpl(kkd_ctx *ctx, const kkd_render_params *rp, float *devFilm,
      * traversal kernels of the other leave idle.  Batches only meet in the film and the counters (atomic adds).
      * $KKD_STREAMS=1 switches back to one lane. */
     int envLanes = (ctx->cfg.flags & KKD_FLAG_ONE_LANE) ? 1 : envLanesDefault;
-    uint64_t batchCap = ctx->cfg.max_samples_in_flight ? ctx->cfg.max_samples_in_flight : std::max<uint64_t>(1ull << 20, (1ull << 26) / perSample);
+    uint64_t batchCap = ctx->cfg.max_samples_in_flight ? ctx->cfg.max_samples_in_flight : std::max<uint64_t>(1ull << 20, (1ull << 28) / perSample);   /* 256 M rays of a kind per launch: ~42 GB of wavefront buffers per lane at one sample of each kind (round 3: 64 M -> 256 M is +1.2 % on C4, every batch ends each traversal stage with an almost idle device); less when the device cannot give that much, below */
     uint64_t batch = 0, nBatches = 0, contCap = 0; size_t S = 0; int nLanes = 1;
     hipError_t e = hipSuccess;
     auto laneP = [&](DevBuf &b, size_t bytes, int lane) { return (char *)b.p + ((bytes + 255) / 256 * 256) * lane; };
-    /* The wavefront buffers are sized by the batch (~0.2 KB per camera sample and lane: 28 GB for two lanes of 64 M samples).
+    /* The wavefront buffers are sized by the batch (~0.16 KB per camera sample and lane with the continuation records: 84 GB for two lanes of 256 M samples).
      * On a device that cannot give that much -- a smaller part, or one shared with other contexts or another tenant -- the
      * batch is halved down to 1 M samples, then the second lane is dropped, before the render gives up with KKD_ERR_NOMEM. */
     for (int attempt = 0;; ++attempt) {
