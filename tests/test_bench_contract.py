@@ -75,7 +75,8 @@ def test_roofline_inputs_are_committed_and_consistent():
         sec, detail = model
         assert 0.5 < detail["issue_slots_per_instruction"] < 2.5 and abs(sum(detail["mix"].values()) - 1) < 1e-2
     pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["c4"]
-    assert abs(pmc["samples_per_batch"] - 3840 * 2160 * 512 / 64) < 0.02 * pmc["samples_per_batch"]      # the headline's batch size
+    # the headline's batch size: 4.25 G camera samples in an even number of equal batches of at most 2^28 (kkd_api.hip) = 16
+    assert abs(pmc["samples_per_batch"] - 3840 * 2160 * 512 / 16) < 0.02 * pmc["samples_per_batch"]
     for stage in ("bsdf", "shadow"):
         st = pmc["stages"][stage]
         assert st["valu_insts_per_launch"] > 0 and st["hbm_bytes_per_launch"] > 0
